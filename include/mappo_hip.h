@@ -1,0 +1,161 @@
+/*
+ * mappo_hip.h — C ABI of libmappo_hip.so: the MI355X (gfx950) hot path of MAPPO training
+ * (rollout forward -> GAE -> PPO minibatch update) as hand-written HIP kernels.
+ *
+ * The reference (Chen001117/mappo) has no FFI on this path: everything is Python/NumPy/torch
+ * (SURVEY.md §8b).  Each entry point therefore cites the reference *Python* site it replaces; the
+ * binding a maintainer would add on the reference side is the ctypes stub in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MAPPO_E* code; mappo_last_error() gives text.
+ *   - all pointers are DEVICE pointers owned by the caller unless marked "host"; no hidden allocation,
+ *     no host synchronisation; work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - all arrays are float32, row-major.  Buffer arrays use the reference's memory order
+ *     [T(+1)][R = n_rollout_threads * num_agents][D] (shared_buffer.py:45-75), so a "flat row" is t*R + r.
+ *   - `rows` arguments are int32 flat rows selecting the minibatch (the generators' fancy indexing,
+ *     shared_buffer.py:246-286, 397-494); NULL means the identity 0..B-1.
+ *   - ValueNorm state is 3 device floats {running_mean, running_mean_sq, debiasing_term} (valuenorm.py:21-23).
+ */
+#ifndef MAPPO_HIP_H
+#define MAPPO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *mappo_stream_t; /* hipStream_t */
+
+#define MAPPO_OK 0
+#define MAPPO_EINVAL (-1)    /* bad argument / unsupported shape */
+#define MAPPO_ELAUNCH (-2)   /* HIP launch error */
+#define MAPPO_ENOTIMPL (-3)  /* valid in the reference but not built here (e.g. popart) */
+
+#define MAPPO_HIDDEN 64      /* hidden_size the MFMA kernels are tiled for (config.py:199 default) */
+#define MAPPO_MAX_ACTIONS 32 /* Discrete(n) with n <= 32 */
+#define MAPPO_MAX_LAYER_N 2
+
+const char *mappo_last_error(void);
+int mappo_abi_version(void);
+
+/* ---- network description -------------------------------------------------------------------------
+ * One actor or critic: MLPBase (mlp.py:31-55) -> [GRU + LayerNorm (rnn.py:7-80)] -> Linear head
+ * (Categorical logits, distributions.py:55-68, or v_out, r_actor_critic.py:136-142).
+ * Parameters live in ONE flat float array in this order (state_dict order minus the unused fc_h):
+ *   feature_norm.{w,b}[in_dim] (if use_feature_norm) | fc1.0.{W[H][in_dim], b[H]} | fc1.2.{w,b}[H] |
+ *   layer_N x { fc2.i.0.{W[H][H], b[H]} | fc2.i.2.{w,b}[H] } |
+ *   (if recurrent) rnn.{weight_ih[3H][H], weight_hh[3H][H], bias_ih[3H], bias_hh[3H]} | rnn.norm.{w,b}[H] |
+ *   head.{W[out_dim][H], b[out_dim]}
+ * mappo_net_param_count() returns the float count; offsets follow from the order above. */
+typedef struct {
+  int32_t in_dim;            /* obs_dim (actor) or share_obs_dim (critic) */
+  int32_t hidden;            /* must be MAPPO_HIDDEN */
+  int32_t out_dim;           /* n actions (actor) or 1 (critic) */
+  int32_t layer_N;           /* config.py:201, 0..MAPPO_MAX_LAYER_N */
+  int32_t use_relu;          /* config.py:203 (0 = tanh) */
+  int32_t use_feature_norm;  /* config.py:208 */
+  int32_t recurrent;         /* use_recurrent_policy || use_naive_recurrent_policy */
+} mappo_net_desc;
+
+int64_t mappo_net_param_count(const mappo_net_desc *desc /*host*/);
+
+/* ---- K2: compute_returns (shared_buffer.py:168-224), all four flag branches ------------------------
+ * Segmented affine-map scan over T: one wavefront per (64 series x time segment), segment composites
+ * combined through LDS.  Writes value_preds[T] <- next_value (GAE branches) or returns[T] <- next_value
+ * (discounted branches) exactly like the reference.  vn_state NULL => no value normaliser. */
+int mappo_gae_scan(const float *rewards /*[T][R]*/, float *value_preds /*[T+1][R]*/,
+                   const float *next_value /*[R]*/, const float *masks /*[T+1][R]*/,
+                   const float *bad_masks /*[T+1][R]*/, float *returns /*[T+1][R]*/,
+                   const float *vn_state /*[3] or NULL*/, int32_t T, int32_t R, float gamma,
+                   float gae_lambda, int32_t use_gae, int32_t use_proper_time_limits,
+                   mappo_stream_t stream);
+
+/* ---- K3: advantage build + normalisation (r_mappo.py:174-182) ---------------------------------------
+ * adv = returns - denorm(value_preds); moments {sum, sum_sq, count} over entries with active != 0
+ * (double accumulation, deterministic two-stage reduction); adv <- (adv - mean) / (std + 1e-5).
+ * The two calls are split so that a multi-GPU caller can all-reduce `moments` in between (§8e C2). */
+int64_t mappo_adv_workspace_bytes(int64_t n);
+int mappo_adv_moments(const float *returns /*[n]*/, const float *value_preds /*[n]*/,
+                      const float *active_masks /*[n]*/, const float *vn_state /*[3] or NULL*/,
+                      float *adv /*[n] out (raw)*/, double *moments /*[3] out*/, void *workspace,
+                      int64_t n, mappo_stream_t stream);
+int mappo_adv_normalize(float *adv /*[n] in/out*/, const double *moments /*[3]*/, int64_t n,
+                        mappo_stream_t stream);
+
+/* ---- K12: ValueNorm (valuenorm.py:37-54) + minibatch denominators ---------------------------------
+ * mappo_minibatch_moments: {sum ret, sum ret^2, sum active, B} over the minibatch rows (double).
+ * mappo_valuenorm_update: EMA update of vn_state from those moments (batch mean = sum/B). */
+int64_t mappo_moments_workspace_bytes(int64_t B);
+int mappo_minibatch_moments(const float *returns, const float *active_masks, const int32_t *rows,
+                            int64_t B, double *mb_moments /*[4] out*/, void *workspace,
+                            mappo_stream_t stream);
+int mappo_valuenorm_update(float *vn_state /*[3] in/out*/, const double *mb_moments /*[4]*/,
+                           double beta, mappo_stream_t stream);
+
+/* ---- K5 (+K6): fused PPO loss forward+backward (r_mappo.py:52-89,124-141; act.py:154-160) ----------
+ * One pass over the minibatch: availability masking, log-softmax, log-prob gather, entropy,
+ * ratio / clipped surrogate, clipped Huber|MSE value error; emits d(actor objective)/d logits,
+ * d(value_loss_coef * value loss)/d values and per-block double partial sums of the 4 statistics.
+ * [B][A] tiles are staged through LDS so that HBM sees only full-line traffic.
+ * Algorithmic bytes per sample: 4*(3A+8) with avail, 4*(2A+8) without. */
+typedef struct {
+  float clip_param, entropy_coef, value_loss_coef, huber_delta;
+  int32_t use_huber_loss, use_clipped_value_loss, use_policy_active_masks, use_value_active_masks,
+      use_valuenorm;
+} mappo_ppo_cfg;
+
+int64_t mappo_ppo_loss_workspace_bytes(int64_t B);
+int mappo_ppo_loss_fwd_bwd(const float *logits /*[B][A] minibatch order, pre-mask*/,
+                           const float *values /*[B] minibatch order*/, const int32_t *rows /*[B]|NULL*/,
+                           const float *avail /*[.][A] buffer order or NULL*/, const float *actions,
+                           const float *old_logp, const float *adv, const float *active,
+                           const float *v_old, const float *returns /*buffer order, indexed by rows*/,
+                           const float *vn_state /*[3] AFTER update, or NULL*/,
+                           const double *mb_moments /*[4] from mappo_minibatch_moments*/,
+                           float *dlogits /*[B][A]*/, float *dvalues /*[B]*/, double *stats /*[6] out:
+                           value_loss, policy_loss, dist_entropy, ratio_mean, sum_active, B*/,
+                           void *workspace, const mappo_ppo_cfg *cfg /*host*/, int64_t B, int32_t A,
+                           mappo_stream_t stream);
+
+/* ---- K7/K6/K8: fused MLP trunk + head on fp32 MFMA (mlp.py:18-28,50-55; act.py:78-81) --------------
+ * Weights resident in LDS, activations of a 32-sample wave tile live in registers/LDS; LayerNorm and
+ * the activation are fused between the v_mfma_f32_32x32x2_f32 chains.
+ *   mappo_mlp_forward : out[B][out_dim] = head(trunk(x[rows]))                       (evaluate / get_values)
+ *   mappo_actor_act   : same trunk + masking + sample|argmax + log-prob               (get_actions / act)
+ *   mappo_mlp_backward: recomputes the forward per tile (no activation round trip through HBM) and
+ *                       accumulates the parameter gradient of sum_b <dout[b], out[b]> into per-block
+ *                       slabs [n_slabs][slab_stride] at column `slab_col0` (flat parameter order). */
+int mappo_mlp_forward(const float *params, const mappo_net_desc *desc /*host*/, const float *x /*[.][in_dim]*/,
+                      const int32_t *rows /*[B] or NULL*/, int64_t B, float *out /*[B][out_dim]*/,
+                      mappo_stream_t stream);
+int mappo_actor_act(const float *params, const mappo_net_desc *desc /*host*/, const float *obs,
+                    const float *avail /*[B][A] or NULL*/, int64_t B, int32_t deterministic,
+                    uint64_t seed, uint64_t counter, float *actions /*[B] fp32 (buffer dtype)*/,
+                    float *logp /*[B]*/, mappo_stream_t stream);
+int32_t mappo_mlp_backward_slabs(int64_t B); /* number of slabs the launch below will write */
+int mappo_mlp_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x,
+                       const int32_t *rows, int64_t B, const float *dout /*[B][out_dim]*/,
+                       float *slabs, int64_t slab_stride, int64_t slab_col0, mappo_stream_t stream);
+
+/* ---- K10/K11: slab reduction, global-norm clip, Adam (r_mappo.py:143-148,157-162; torch Adam) -------
+ * The flat gradient covers `n_seg` parameter segments (actor, critic); norms/clip/lr are per segment.
+ * opt_hyper (device floats, per segment, stride 8): {lr, beta1, beta2, eps, weight_decay, max_grad_norm,
+ * use_clip, enabled}.  opt_step: device int32 per segment (Adam's `step`, incremented by the call).
+ * grad_norms out: device floats per segment (pre-clip norm, what train_info logs). */
+int64_t mappo_optim_workspace_bytes(int64_t P);
+int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t slab_stride, int64_t P,
+                      float *grad /*[P] out*/, mappo_stream_t stream);
+int mappo_clip_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
+                    const int64_t *seg_bounds /*host, [n_seg+1], multiples of 256*/, int32_t n_seg,
+                    const float *opt_hyper, int32_t *opt_step, float *grad_norms, void *workspace,
+                    mappo_stream_t stream);
+
+/* ---- self test: fp32 MFMA operand/accumulator lane maps (used by tests/, not by the product path) --- */
+int mappo_selftest_mfma(const float *A /*[32][2]*/, const float *Bm /*[2][32]*/, float *D /*[32][32]*/,
+                        mappo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPPO_HIP_H */

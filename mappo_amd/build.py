@@ -1,0 +1,59 @@
+"""Build libmappo_hip.so (gfx950) in-tree with hipcc.  `python -m mappo_amd.build [--force]`."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmappo_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-variable", "-Wno-unused-but-set-variable"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    srcs = sources()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(os.path.dirname(HERE), "include", "mappo_hip.h"))
+    objs = []
+    procs = []
+    for s in srcs:
+        o = s[:-4] + ".o"
+        objs.append(o)
+        if force or _stale(o, [s] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = False
+    for s, p in procs:
+        out, _ = p.communicate()
+        if out.strip() and verbose:
+            print(out)
+        if p.returncode != 0:
+            failed = True
+            print(f"FAILED: {s}\n{out}", file=sys.stderr)
+    if failed:
+        raise RuntimeError("hipcc failed")
+    if force or procs or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

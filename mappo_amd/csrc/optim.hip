@@ -1,0 +1,147 @@
+// optim.hip — K10 + K11: gradient slab reduction, global-norm clipping and Adam on ONE flat buffer.
+//   clip : torch.nn.utils.clip_grad_norm_ (r_mappo.py:143-146,157-160): norm = ||g||_2 over the segment,
+//          coef = min(1, max_norm / (norm + 1e-6)), the PRE-clip norm is what train_info logs.
+//   Adam : torch.optim.Adam defaults + eps=opti_eps (rMAPPOPolicy.py:31-37):
+//          m += (g-m)(1-b1); v = v*b2 + g*g*(1-b2); p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+// The flat buffer holds `n_seg` segments (actor | critic), each a multiple of 256 floats so that a
+// 256-thread block never straddles two segments.  Step counters and hyper-parameters are device resident
+// (lr_decay just rewrites one float), so the whole update is capturable in a hipGraph.
+#include "common.h"
+
+#define OPT_BLOCK 256
+#define OPT_MAX_SEG 4
+
+struct SegBounds {
+  int64_t b[OPT_MAX_SEG + 1];
+  int n;
+};
+
+__device__ __forceinline__ int seg_of(const SegBounds &sb, int64_t i) {
+  int s = 0;
+#pragma unroll
+  for (int k = 1; k < OPT_MAX_SEG; ++k)
+    if (k < sb.n && i >= sb.b[k]) s = k;
+  return s;
+}
+
+// grad[p] = sum over slabs (per-workgroup partial gradients written by mappo_mlp_backward); coalesced in p.
+__global__ __launch_bounds__(OPT_BLOCK) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs,
+                                                               int64_t stride, int64_t P, float *__restrict__ grad) {
+  const int64_t p = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x;
+  if (p >= P) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int s = 0;
+  for (; s + 4 <= n_slabs; s += 4) {
+    s0 += slabs[(size_t)(s + 0) * stride + p];
+    s1 += slabs[(size_t)(s + 1) * stride + p];
+    s2 += slabs[(size_t)(s + 2) * stride + p];
+    s3 += slabs[(size_t)(s + 3) * stride + p];
+  }
+  for (; s < n_slabs; ++s) s0 += slabs[(size_t)s * stride + p];
+  grad[p] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(OPT_BLOCK) void sqnorm_partial_kernel(const float *__restrict__ grad, int64_t P,
+                                                                  double *__restrict__ partials) {
+  __shared__ double smem[16];
+  const int64_t p = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x;
+  double v[1] = {0.0};
+  if (p < P) { const double g = (double)grad[p]; v[0] = g * g; }
+  block_sum<1>(v, smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+// One block: per-segment norm, clip coefficient, step increment, bias corrections.
+// seg_ws[s*4 + {0,1,2,3}] = {clip coef, step_size = lr/(1-b1^t), sqrt(1-b2^t), enabled}
+__global__ __launch_bounds__(OPT_BLOCK) void norm_finalize_kernel(const double *__restrict__ partials, SegBounds sb,
+                                                                 const float *__restrict__ hyper, int32_t *step,
+                                                                 float *__restrict__ grad_norms, float *__restrict__ seg_ws) {
+  __shared__ double smem[16];
+  for (int s = 0; s < sb.n; ++s) {
+    const int b0 = (int)(sb.b[s] / OPT_BLOCK), b1 = (int)(sb.b[s + 1] / OPT_BLOCK);
+    double v[1] = {0.0};
+    for (int b = b0 + threadIdx.x; b < b1; b += blockDim.x) v[0] += partials[b];
+    block_sum<1>(v, smem);
+    if (threadIdx.x == 0) {
+      const float *h = hyper + s * 8;
+      const float norm = (float)sqrt(v[0]);
+      const bool enabled = h[7] != 0.f;
+      float coef = 1.f;
+      if (h[6] != 0.f) coef = fminf(h[5] / (norm + 1e-6f), 1.f);
+      int t = step[s];
+      if (enabled) { t += 1; step[s] = t; }
+      const double bc1 = 1.0 - pow((double)h[1], (double)t);
+      const double bc2 = 1.0 - pow((double)h[2], (double)t);
+      grad_norms[s] = norm;
+      seg_ws[s * 4 + 0] = coef;
+      seg_ws[s * 4 + 1] = (float)((double)h[0] / (bc1 > 0.0 ? bc1 : 1.0));
+      seg_ws[s * 4 + 2] = (float)sqrt(bc2 > 0.0 ? bc2 : 1.0);
+      seg_ws[s * 4 + 3] = enabled ? 1.f : 0.f;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(OPT_BLOCK) void adam_kernel(float *__restrict__ params, const float *__restrict__ grad,
+                                                        float *__restrict__ m, float *__restrict__ v, SegBounds sb,
+                                                        const float *__restrict__ hyper, const float *__restrict__ seg_ws) {
+  const int64_t i = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x;
+  if (i >= sb.b[sb.n]) return;
+  const int s = seg_of(sb, (int64_t)blockIdx.x * OPT_BLOCK);
+  const float *h = hyper + s * 8;
+  const float *w = seg_ws + s * 4;
+  if (w[3] == 0.f) return;
+  const float b1 = h[1], b2 = h[2], eps = h[3], wd = h[4];
+  float g = grad[i] * w[0];
+  float p = params[i];
+  if (wd != 0.f) g = g + wd * p;
+  float mi = m[i], vi = v[i];
+  mi = mi + (g - mi) * (1.f - b1);
+  vi = vi * b2 + g * g * (1.f - b2);
+  const float denom = sqrtf(vi) / w[2] + eps;
+  p = p - w[1] * (mi / denom);
+  params[i] = p; m[i] = mi; v[i] = vi;
+}
+
+extern "C" int64_t mappo_optim_workspace_bytes(int64_t P) {
+  const int64_t nblk = (P + OPT_BLOCK - 1) / OPT_BLOCK;
+  return nblk * (int64_t)sizeof(double) + OPT_MAX_SEG * 4 * (int64_t)sizeof(float) + 64;
+}
+
+extern "C" int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t slab_stride, int64_t P, float *grad,
+                                 mappo_stream_t stream) {
+  MAPPO_REQUIRE(slabs && grad && n_slabs > 0 && P > 0 && slab_stride >= P, "slab_reduce: bad arguments");
+  const int nblk = (int)((P + OPT_BLOCK - 1) / OPT_BLOCK);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, as_stream(stream), slabs, (int)n_slabs,
+                     slab_stride, P, grad);
+  MAPPO_CHECK_LAUNCH("slab_reduce");
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_clip_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
+                               const int64_t *seg_bounds, int32_t n_seg, const float *opt_hyper, int32_t *opt_step,
+                               float *grad_norms, void *workspace, mappo_stream_t stream) {
+  MAPPO_REQUIRE(params && grad && exp_avg && exp_avg_sq && seg_bounds && opt_hyper && opt_step && grad_norms && workspace,
+                "clip_adam: null pointer");
+  MAPPO_REQUIRE(n_seg >= 1 && n_seg <= OPT_MAX_SEG, "clip_adam: n_seg=%d", n_seg);
+  SegBounds sb;
+  sb.n = n_seg;
+  for (int s = 0; s <= n_seg; ++s) {
+    MAPPO_REQUIRE(seg_bounds[s] % OPT_BLOCK == 0 && (s == 0 || seg_bounds[s] > seg_bounds[s - 1]),
+                  "clip_adam: segment bounds must be increasing multiples of %d", OPT_BLOCK);
+    sb.b[s] = seg_bounds[s];
+  }
+  MAPPO_REQUIRE(seg_bounds[0] == 0, "clip_adam: seg_bounds[0] must be 0");
+  const int64_t P = seg_bounds[n_seg];
+  const int nblk = (int)(P / OPT_BLOCK);
+  double *partials = (double *)workspace;
+  float *seg_ws = (float *)((char *)workspace + (((size_t)nblk * sizeof(double) + 63) / 64) * 64);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, grad, P, partials);
+  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(OPT_BLOCK), 0, st, (const double *)partials, sb, opt_hyper,
+                     opt_step, grad_norms, seg_ws);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, params, grad, exp_avg, exp_avg_sq, sb, opt_hyper,
+                     (const float *)seg_ws);
+  MAPPO_CHECK_LAUNCH("clip_adam");
+  return MAPPO_OK;
+}

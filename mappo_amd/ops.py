@@ -1,0 +1,157 @@
+"""Tensor-level wrappers over the C ABI (include/mappo_hip.h).  torch is plumbing here: device memory,
+streams, shapes.  Every function enqueues on torch's current stream of the tensors' device and returns
+without synchronising."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import NetDesc, PpoCfg
+
+
+def _ptr(t, dtype=torch.float32, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("tensor required")
+    if not t.is_cuda:
+        raise _lib.MappoHipError("mappo_amd ops need tensors in HBM (cuda/hip device); got a CPU tensor — "
+                                 "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+
+
+def net_desc(in_dim, out_dim, layer_N=1, use_relu=True, use_feature_norm=True, recurrent=False, hidden=64):
+    return NetDesc(int(in_dim), int(hidden), int(out_dim), int(layer_N), int(bool(use_relu)),
+                   int(bool(use_feature_norm)), int(bool(recurrent)))
+
+
+def net_param_count(desc):
+    return int(_lib.load().mappo_net_param_count(C.byref(desc)))
+
+
+# ---- K2 -------------------------------------------------------------------------------------------
+def gae_scan(rewards, value_preds, next_value, masks, bad_masks, returns, vn_state, gamma, gae_lambda,
+             use_gae=True, use_proper_time_limits=False):
+    """compute_returns (shared_buffer.py:168-224) in place on [T(+1), R] views of the buffer arrays."""
+    T = rewards.shape[0]
+    R = rewards.numel() // T
+    lib = _lib.load()
+    rc = lib.mappo_gae_scan(_ptr(rewards), _ptr(value_preds), _ptr(next_value), _ptr(masks),
+                            _ptr(bad_masks, allow_none=True), _ptr(returns), _ptr(vn_state, allow_none=True),
+                            T, R, float(gamma), float(gae_lambda), int(bool(use_gae)),
+                            int(bool(use_proper_time_limits)), _stream())
+    _lib.check(rc, "mappo_gae_scan")
+
+
+# ---- K3 -------------------------------------------------------------------------------------------
+def adv_moments(returns, value_preds, active_masks, vn_state, adv, moments, workspace=None):
+    lib = _lib.load()
+    n = adv.numel()
+    if workspace is None:
+        workspace = _ws(lib.mappo_adv_workspace_bytes(n), adv.device)
+    rc = lib.mappo_adv_moments(_ptr(returns), _ptr(value_preds), _ptr(active_masks), _ptr(vn_state, allow_none=True),
+                               _ptr(adv), _ptr(moments, torch.float64), _ptr(workspace, torch.uint8), n, _stream())
+    _lib.check(rc, "mappo_adv_moments")
+
+
+def adv_normalize(adv, moments):
+    rc = _lib.load().mappo_adv_normalize(_ptr(adv), _ptr(moments, torch.float64), adv.numel(), _stream())
+    _lib.check(rc, "mappo_adv_normalize")
+
+
+# ---- K12 ------------------------------------------------------------------------------------------
+def minibatch_moments(returns, active_masks, rows, B, mb_moments, workspace=None):
+    lib = _lib.load()
+    if workspace is None:
+        workspace = _ws(lib.mappo_moments_workspace_bytes(B), returns.device)
+    rc = lib.mappo_minibatch_moments(_ptr(returns), _ptr(active_masks), _ptr(rows, torch.int32, allow_none=True), int(B),
+                                     _ptr(mb_moments, torch.float64), _ptr(workspace, torch.uint8), _stream())
+    _lib.check(rc, "mappo_minibatch_moments")
+
+
+def valuenorm_update(vn_state, mb_moments, beta=0.99999):
+    rc = _lib.load().mappo_valuenorm_update(_ptr(vn_state), _ptr(mb_moments, torch.float64), float(beta), _stream())
+    _lib.check(rc, "mappo_valuenorm_update")
+
+
+# ---- K5 -------------------------------------------------------------------------------------------
+def ppo_cfg(args):
+    return PpoCfg(float(args.clip_param), float(args.entropy_coef), float(args.value_loss_coef), float(args.huber_delta),
+                  int(bool(args.use_huber_loss)), int(bool(args.use_clipped_value_loss)),
+                  int(bool(args.use_policy_active_masks)), int(bool(args.use_value_active_masks)),
+                  int(bool(args.use_valuenorm)))
+
+
+def ppo_loss_fwd_bwd(logits, values, rows, avail, actions, old_logp, adv, active, v_old, returns, vn_state, mb_moments,
+                     dlogits, dvalues, stats, cfg, workspace=None):
+    lib = _lib.load()
+    B, A = logits.shape
+    if workspace is None:
+        workspace = _ws(lib.mappo_ppo_loss_workspace_bytes(B), logits.device)
+    rc = lib.mappo_ppo_loss_fwd_bwd(_ptr(logits), _ptr(values), _ptr(rows, torch.int32, allow_none=True),
+                                    _ptr(avail, allow_none=True), _ptr(actions), _ptr(old_logp), _ptr(adv), _ptr(active),
+                                    _ptr(v_old), _ptr(returns), _ptr(vn_state, allow_none=True),
+                                    _ptr(mb_moments, torch.float64), _ptr(dlogits), _ptr(dvalues),
+                                    _ptr(stats, torch.float64), _ptr(workspace, torch.uint8), C.byref(cfg), int(B), int(A),
+                                    _stream())
+    _lib.check(rc, "mappo_ppo_loss_fwd_bwd")
+
+
+# ---- K7 / K8 --------------------------------------------------------------------------------------
+def mlp_forward(params, desc, x, rows, B, out):
+    rc = _lib.load().mappo_mlp_forward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True),
+                                       int(B), _ptr(out), _stream())
+    _lib.check(rc, "mappo_mlp_forward")
+
+
+def actor_act(params, desc, obs, avail, B, deterministic, seed, counter, actions, logp):
+    rc = _lib.load().mappo_actor_act(_ptr(params), C.byref(desc), _ptr(obs), _ptr(avail, allow_none=True), int(B),
+                                     int(bool(deterministic)), int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
+                                     _ptr(actions), _ptr(logp), _stream())
+    _lib.check(rc, "mappo_actor_act")
+
+
+def mlp_backward_slabs(B):
+    return int(_lib.load().mappo_mlp_backward_slabs(int(B)))
+
+
+def mlp_backward(params, desc, x, rows, B, dout, slabs, slab_stride, slab_col0):
+    rc = _lib.load().mappo_mlp_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True),
+                                        int(B), _ptr(dout), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+    _lib.check(rc, "mappo_mlp_backward")
+
+
+# ---- K10 / K11 ------------------------------------------------------------------------------------
+def slab_reduce(slabs, n_slabs, slab_stride, P, grad):
+    rc = _lib.load().mappo_slab_reduce(_ptr(slabs), int(n_slabs), int(slab_stride), int(P), _ptr(grad), _stream())
+    _lib.check(rc, "mappo_slab_reduce")
+
+
+def optim_workspace(P, device):
+    return _ws(_lib.load().mappo_optim_workspace_bytes(int(P)), device)
+
+
+def clip_adam(params, grad, exp_avg, exp_avg_sq, seg_bounds, opt_hyper, opt_step, grad_norms, workspace):
+    n_seg = len(seg_bounds) - 1
+    arr = (C.c_int64 * (n_seg + 1))(*[int(b) for b in seg_bounds])
+    rc = _lib.load().mappo_clip_adam(_ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), arr, n_seg,
+                                     _ptr(opt_hyper), _ptr(opt_step, torch.int32), _ptr(grad_norms),
+                                     _ptr(workspace, torch.uint8), _stream())
+    _lib.check(rc, "mappo_clip_adam")
+
+
+def selftest_mfma(A, Bm, D):
+    rc = _lib.load().mappo_selftest_mfma(_ptr(A), _ptr(Bm), _ptr(D), _stream())
+    _lib.check(rc, "mappo_selftest_mfma")

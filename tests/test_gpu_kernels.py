@@ -1,0 +1,472 @@
+"""GPU parity tests: every HIP kernel, called through the C ABI (mappo_amd.ops -> libmappo_hip.so), against
+the CPU oracle (oracle/mappo_oracle.py) and, where they exist, the committed golden vectors of the reference.
+
+Tolerances: bit-exact for indices / actions / masks; 1e-5 relative (north_star) for fp32 returns, losses and
+forward outputs, with an absolute floor of 1e-6 where values cross zero.  Gradients of a 76 800-term fp32 sum
+are compared at 1e-4 relative to the tensor's max magnitude (re-association of the sum; the oracle itself
+differs from the reference by 5e-7 there, see tests/test_oracle_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, sub
+from oracle import mappo_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda()
+
+
+def close(a, b, rtol=1e-5, atol=1e-6, msg=""):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    np.testing.assert_allclose(a.astype(np.float64), b.astype(np.float64), rtol=rtol, atol=atol, err_msg=msg)
+
+
+def close_rel_max(a, b, tol=1e-4, msg=""):
+    a = a.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-12)
+    err = np.abs(a - b).max() / scale
+    assert err <= tol, f"{msg}: max err / max|ref| = {err:.3e} > {tol}"
+
+
+@pytest.fixture(scope="module")
+def ops(gpu_device):
+    from mappo_amd import ops as _ops
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_mfma_lane_maps(ops):
+    """v_mfma_f32_32x32x2_f32 operand / accumulator lane maps, asymmetric data (cdna guide §3)."""
+    rng = np.random.default_rng(0)
+    A = rng.integers(-8, 9, (32, 2)).astype(np.float32)
+    B = rng.integers(-8, 9, (2, 32)).astype(np.float32)
+    D = torch.zeros(32, 32, device="cuda")
+    ops.selftest_mfma(dev(A), dev(B), D)
+    np.testing.assert_array_equal(D.cpu().numpy(), A @ B)
+
+
+# ------------------------------------------------------------------------------------------------------
+def _run_gae(ops, rewards, value_preds, masks, bad_masks, next_value, vn_state, gamma, lam, use_gae, ptl):
+    T = rewards.shape[0]
+    R = rewards[0].size
+    rw, vp, mk, bm = dev(rewards.reshape(T, R)), dev(value_preds.reshape(T + 1, R)), dev(masks.reshape(T + 1, R)), dev(bad_masks.reshape(T + 1, R))
+    ret = torch.zeros(T + 1, R, device="cuda")
+    nv = dev(next_value.reshape(R))
+    vs = dev(vn_state) if vn_state is not None else None
+    ops.gae_scan(rw, vp, nv, mk, bm, ret, vs, gamma, lam, use_gae, ptl)
+    return ret.cpu().numpy(), vp.cpu().numpy()
+
+
+def test_gae_golden_all_branches(ops):
+    g = golden("gae")
+    for c in range(int(g["n_cases"])):
+        d = sub(g, f"c{c}")
+        use_gae, ptl, use_vn = [bool(x) for x in d["flags"]]
+        ret, vp = _run_gae(ops, d["rewards"], d["value_preds"], d["masks"], d["bad_masks"], d["next_value"],
+                           d["vn_state"] if use_vn else None, float(d["hyper"][0]), float(d["hyper"][1]), use_gae, ptl)
+        close(ret.reshape(d["returns"].shape), d["returns"], 1e-5, 2e-6, f"gae case {c}")
+        if use_gae:
+            np.testing.assert_array_equal(vp.reshape(d["value_preds_after"].shape), d["value_preds_after"])
+
+
+@pytest.mark.parametrize("T,N,M", [(25, 1024, 3), (400, 64, 3), (1100, 5, 3), (1, 3, 2), (33, 7, 1)])
+def test_gae_vs_oracle_sizes(ops, T, N, M):
+    """BASELINE config-2 size, SMAC-length episodes, the multi-chunk path (T > 512), ragged R."""
+    rng = np.random.default_rng(T * 1000 + N)
+    f = np.float32
+    rewards = rng.standard_normal((T, N, M, 1)).astype(f)
+    vp = rng.standard_normal((T + 1, N, M, 1)).astype(f)
+    masks = (rng.random((T + 1, N, M, 1)) > 0.1).astype(f)
+    bad = (rng.random((T + 1, N, M, 1)) > 0.1).astype(f)
+    nv = rng.standard_normal((N, M, 1)).astype(f)
+    vn = O.ValueNormRef(); vn.update(rng.standard_normal((64, 1)).astype(f) * 2 + 1)
+    for use_gae in (True, False):
+        for ptl in (False, True):
+            ref = O.compute_returns_ref(rewards, vp.copy(), masks, bad, nv, 0.99, 0.95, use_gae, ptl, vn.denormalize)
+            ret, _ = _run_gae(ops, rewards, vp, masks, bad, nv, vn.state(), 0.99, 0.95, use_gae, ptl)
+            close(ret.reshape(ref.shape), ref, 1e-5, 1e-5 if T > 500 else 3e-6, f"T={T} gae={use_gae} ptl={ptl}")
+
+
+def test_gae_property_linearity(ops):
+    """Size-independent property at full size: without value bootstrap, returns are linear in the rewards."""
+    T, R = 400, 16384
+    g = torch.Generator(device="cuda").manual_seed(3)
+    r1 = torch.randn(T, R, device="cuda", generator=g)
+    r2 = torch.randn(T, R, device="cuda", generator=g)
+    masks = (torch.rand(T + 1, R, device="cuda", generator=g) > 0.05).float()
+    zeros = torch.zeros(T + 1, R, device="cuda")
+    nv = torch.zeros(R, device="cuda")
+    outs = []
+    for rw in (r1, r2, r1 + 2 * r2):
+        ret = torch.zeros(T + 1, R, device="cuda")
+        ops.gae_scan(rw.contiguous(), zeros.clone(), nv, masks, None, ret, None, 0.99, 0.95, True, False)
+        outs.append(ret)
+    close(outs[2], outs[0] + 2 * outs[1], 1e-4, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_advantage_golden_and_oracle(ops):
+    g = golden("advnorm")
+    for c in range(int(g["n_cases"])):
+        d = sub(g, f"c{c}")
+        use_vn = bool(d["use_vn"])
+        n = d["adv"].size
+        adv = torch.zeros(n, device="cuda")
+        mom = torch.zeros(3, dtype=torch.float64, device="cuda")
+        ops.adv_moments(dev(d["returns"][:-1].reshape(-1)), dev(d["value_preds"][:-1].reshape(-1)),
+                        dev(d["active_masks"][:-1].reshape(-1)), dev(d["vn_state"]) if use_vn else None, adv, mom)
+        ops.adv_normalize(adv, mom)
+        close(adv.cpu().numpy().reshape(d["adv"].shape), d["adv"], 1e-5, 2e-6)
+        m = mom.cpu().numpy()
+        close(m[0] / m[2], d["mean"], 1e-5, 1e-6)
+    # BASELINE config-2 size against the oracle
+    rng = np.random.default_rng(5)
+    T, R = 25, 3072
+    ret = rng.standard_normal((T + 1, R, 1)).astype(np.float32) * 3
+    vp = rng.standard_normal((T + 1, R, 1)).astype(np.float32)
+    act = (rng.random((T + 1, R, 1)) > 0.2).astype(np.float32)
+    vn = O.ValueNormRef(); vn.update(ret[:5].reshape(-1, 1))
+    ref, mean, std = O.normalized_advantages_ref(ret, vp, act, vn.denormalize)
+    adv = torch.zeros(T * R, device="cuda")
+    mom = torch.zeros(3, dtype=torch.float64, device="cuda")
+    ops.adv_moments(dev(ret[:-1].reshape(-1)), dev(vp[:-1].reshape(-1)), dev(act[:-1].reshape(-1)), dev(vn.state()), adv, mom)
+    ops.adv_normalize(adv, mom)
+    close(adv.cpu().numpy(), ref.reshape(-1), 1e-5, 3e-6)
+
+
+def test_valuenorm_update(ops):
+    g = golden("valuenorm")
+    st = torch.zeros(3, device="cuda")
+    for i in range(4):
+        x = g[f"x{i}"].reshape(-1)
+        mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+        ops.minibatch_moments(dev(x), torch.ones(x.size, device="cuda"), None, x.size, mom)
+        ops.valuenorm_update(st, mom)
+        close(st, g[f"state{i}"], 2e-6, 1e-9)
+    # gathered rows
+    rng = np.random.default_rng(1)
+    ret = rng.standard_normal(5000).astype(np.float32)
+    act = (rng.random(5000) > 0.3).astype(np.float32)
+    rows = rng.permutation(5000)[:3000].astype(np.int32)
+    mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ops.minibatch_moments(dev(ret), dev(act), dev(rows, torch.int32), 3000, mom)
+    m = mom.cpu().numpy()
+    close(m, [ret[rows].astype(np.float64).sum(), (ret[rows].astype(np.float64) ** 2).sum(), act[rows].sum(), 3000], 1e-12, 1e-9)
+
+
+# ------------------------------------------------------------------------------------------------------
+def _loss_case(ops, B, A, n_rows, seed, with_rows, with_avail, **flags):
+    rng = np.random.default_rng(seed)
+    f = np.float32
+    a = O.default_args(**flags)
+    logits = (rng.standard_normal((B, A)) * 2).astype(f)
+    values = rng.standard_normal(B).astype(f)
+    rows = rng.permutation(n_rows)[:B].astype(np.int32) if with_rows else np.arange(B, dtype=np.int32)
+    avail = (rng.random((n_rows, A)) > 0.3).astype(f)
+    actions = rng.integers(0, A, n_rows).astype(f)
+    avail[np.arange(n_rows), actions.astype(int)] = 1.0
+    old_logp = (-np.abs(rng.standard_normal(n_rows)) - 0.3).astype(f)
+    adv = rng.standard_normal(n_rows).astype(f)
+    active = (rng.random(n_rows) > 0.25).astype(f)
+    v_old = (values.mean() + rng.standard_normal(n_rows) * 0.3).astype(f)
+    v_old[rows] = values + rng.standard_normal(B).astype(f) * 0.25       # both sides of the clip range
+    ret = (rng.standard_normal(n_rows) * 4).astype(f)
+    ret[rng.random(n_rows) > 0.9] *= 20                                    # Huber's linear branch
+    vn = O.ValueNormRef(); vn.update(ret[:50].reshape(-1, 1))
+    vn.update(ret[rows].reshape(-1, 1))
+    mean, var = vn.mean_var()
+    ref = O.ppo_loss_fwd_bwd_ref(logits, avail[rows] if with_avail else None, actions[rows], old_logp[rows], adv[rows],
+                                 active[rows], values, v_old[rows], ret[rows], float(mean), float(var), a.clip_param,
+                                 a.entropy_coef, a.value_loss_coef, a.huber_delta, a.use_huber_loss,
+                                 a.use_clipped_value_loss, a.use_policy_active_masks, a.use_value_active_masks,
+                                 a.use_valuenorm)
+    mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+    d_rows = dev(rows, torch.int32) if with_rows else None
+    ops.minibatch_moments(dev(ret), dev(active), d_rows, B, mom)
+    dl, dv = torch.zeros(B, A, device="cuda"), torch.zeros(B, device="cuda")
+    stats = torch.zeros(6, dtype=torch.float64, device="cuda")
+    ops.ppo_loss_fwd_bwd(dev(logits), dev(values), d_rows, dev(avail) if with_avail else None, dev(actions), dev(old_logp),
+                         dev(adv), dev(active), dev(v_old), dev(ret), dev(vn.state()), mom, dl, dv, stats, ops.ppo_cfg(a))
+    s = stats.cpu().numpy()
+    close(s[0], ref["value_loss"], 1e-5, 1e-7, "value_loss")
+    close(s[1], ref["policy_loss"], 1e-5, 1e-7, "policy_loss")
+    close(s[2], ref["dist_entropy"], 1e-5, 1e-7, "entropy")
+    close(s[3], ref["ratio_mean"], 1e-5, 1e-7, "ratio")
+    assert s[4] == active[rows].sum() and s[5] == B
+    close_rel_max(dl, ref["dlogits"], 2e-5, "dlogits")
+    close_rel_max(dv, ref["dvalues"], 2e-5, "dvalues")
+
+
+@pytest.mark.parametrize("B,A", [(600, 5), (76800, 5), (1000, 9), (777, 18), (256, 1), (300, 32)])
+def test_ppo_loss_sizes(ops, B, A):
+    _loss_case(ops, B, A, B + 123, B + A, with_rows=True, with_avail=True)
+    _loss_case(ops, B, A, B, B + A + 1, with_rows=False, with_avail=False)
+
+
+@pytest.mark.parametrize("flags", [dict(use_huber_loss=False), dict(use_clipped_value_loss=False),
+                                   dict(use_policy_active_masks=False, use_value_active_masks=False),
+                                   dict(use_valuenorm=False), dict(clip_param=0.05, entropy_coef=0.1, value_loss_coef=0.5,
+                                                                   huber_delta=1.0)])
+def test_ppo_loss_flag_variants(ops, flags):
+    _loss_case(ops, 2000, 5, 2500, 11, with_rows=True, with_avail=True, **flags)
+
+
+def test_ppo_loss_golden_sample(ops):
+    """The reference's own ppo_update sample (golden c0): losses as returned by R_MAPPO.ppo_update."""
+    g = golden("ppo_update")
+    d = sub(g, "c0")
+    T, N, M, D, S, A, H = [int(x) for x in d["dims"]]
+    a = O.default_args(hidden_size=H, lr=7e-4, critic_lr=7e-4)
+    pol = O.PolicyRef(a, D, S, A)
+    pol.actor.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sub(g, "c0/actor0").items()})
+    pol.critic.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sub(g, "c0/critic0").items()})
+    sm = {k: d[f"sample/{k}"] for k in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds",
+                                        "returns", "masks", "active_masks", "old_action_log_probs", "adv_targ", "available_actions")}
+    t = torch.from_numpy
+    with torch.no_grad():
+        feats, _ = pol.actor.features(t(sm["obs"]), t(sm["rnn_states"]), t(sm["masks"]))
+        logits = pol.actor.act.action_out.linear(feats).numpy()
+        values = pol.critic(t(sm["share_obs"]), t(sm["rnn_states_critic"]), t(sm["masks"]))[0].numpy().reshape(-1)
+    B = logits.shape[0]
+    vn = torch.tensor(d["vn0"]).cuda()
+    mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ret, act = dev(sm["returns"].reshape(-1)), dev(sm["active_masks"].reshape(-1))
+    ops.minibatch_moments(ret, act, None, B, mom)
+    ops.valuenorm_update(vn, mom)
+    close(vn, d["r0/vn"], 2e-6, 1e-9)
+    dl, dv = torch.zeros(B, A, device="cuda"), torch.zeros(B, device="cuda")
+    stats = torch.zeros(6, dtype=torch.float64, device="cuda")
+    ops.ppo_loss_fwd_bwd(dev(logits), dev(values), None, dev(sm["available_actions"]), dev(sm["actions"].reshape(-1)),
+                         dev(sm["old_action_log_probs"].reshape(-1)), dev(sm["adv_targ"].reshape(-1)), act,
+                         dev(sm["value_preds"].reshape(-1)), ret, vn, mom, dl, dv, stats, ops.ppo_cfg(a))
+    s = stats.cpu().numpy()
+    ref = d["r0/stats"]          # value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, ratio
+    close([s[0], s[1], s[2], s[3]], [ref[0], ref[2], ref[3], ref[5]], 1e-5, 1e-7)
+
+
+# ------------------------------------------------------------------------------------------------------
+def _flat_from_module(ops, module, desc, head_prefix):
+    from mappo_amd import flat
+    layout, P = flat.net_layout(desc, head_prefix)
+    assert P == ops.net_param_count(desc)
+    buf = torch.zeros(P)
+    flat.pack_state_dict(buf, layout, {k: v.detach() for k, v in module.state_dict().items()})
+    return buf.cuda(), layout, P
+
+
+def _randomize(module, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n_, p_ in module.named_parameters():
+            if "norm" in n_ or "bias" in n_ or ".2." in n_:
+                p_.add_(0.2 * torch.randn(p_.shape, generator=g))
+            if "action_out" in n_ and "weight" in n_:
+                p_.mul_(40.0)
+
+
+NET_CASES = [  # D, A, relu, layer_N, feature_norm, B
+    (18, 5, True, 1, True, 3072), (54, 1, True, 1, True, 3072), (18, 5, False, 1, True, 700), (54, 1, False, 1, True, 100),
+    (30, 9, True, 1, True, 333), (48, 1, True, 1, True, 64), (64, 18, True, 1, False, 257), (7, 3, True, 0, True, 90),
+    (33, 32, False, 2, True, 130), (18, 5, True, 1, True, 1)]
+
+
+@pytest.mark.parametrize("D,A,relu,LN,fn,B", NET_CASES)
+def test_mlp_forward_vs_oracle(ops, D, A, relu, LN, fn, B):
+    torch.manual_seed(D * 100 + A)
+    a = O.default_args(use_ReLU=relu, layer_N=LN, use_feature_normalization=fn)
+    net = O.ActorRef(a, D, A) if A > 1 else O.CriticRef(a, D)
+    _randomize(net, 7)
+    desc = ops.net_desc(D, A, LN, relu, fn)
+    params, _, _ = _flat_from_module(ops, net, desc, "act.action_out.linear" if A > 1 else "v_out")
+    rng = np.random.default_rng(B)
+    n_rows = B + 50
+    x = rng.standard_normal((n_rows, D)).astype(np.float32) * 2
+    rows = rng.permutation(n_rows)[:B].astype(np.int32)
+    with torch.no_grad():
+        xt = torch.from_numpy(x[rows])
+        if A > 1:
+            feats, _ = net.features(xt, None, None)
+            ref = net.act.action_out.linear(feats).numpy()
+        else:
+            ref = net(xt, None, None)[0].numpy()
+    out = torch.zeros(B, A, device="cuda")
+    ops.mlp_forward(params, desc, dev(x), dev(rows, torch.int32), B, out)
+    close(out, ref, 1e-5, 2e-5 if A > 1 else 2e-6, f"forward D={D} A={A}")
+    # identity rows
+    out2 = torch.zeros(B, A, device="cuda")
+    ops.mlp_forward(params, desc, dev(x[rows]), None, B, out2)
+    np.testing.assert_array_equal(out.cpu().numpy(), out2.cpu().numpy())
+
+
+def test_forward_golden_reference_outputs(ops):
+    """get_actions(deterministic) / get_values / evaluate_actions of the reference itself (golden forward c0, c1)."""
+    g = golden("forward")
+    for c in (0, 1):
+        d = sub(g, f"c{c}")
+        relu, rec, D, S, A, B, H = [int(x) for x in d["spec"]]
+        from mappo_amd import flat
+        da, dc = ops.net_desc(D, A, 1, relu, True), ops.net_desc(S, 1, 1, relu, True)
+        la, Pa = flat.net_layout(da, "act.action_out.linear")
+        lc, Pc = flat.net_layout(dc, "v_out")
+        pa, pc = torch.zeros(Pa), torch.zeros(Pc)
+        flat.pack_state_dict(pa, la, sub(g, f"c{c}/actor")); flat.pack_state_dict(pc, lc, sub(g, f"c{c}/critic"))
+        pa, pc = pa.cuda(), pc.cuda()
+        for tag in ("avail", "noavail"):
+            av = dev(d["avail"]) if tag == "avail" else None
+            actions, logp = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+            ops.actor_act(pa, da, dev(d["obs"]), av, B, True, 1, 0, actions, logp)
+            np.testing.assert_array_equal(actions.cpu().numpy().astype(np.int64), d[f"{tag}/actions"].reshape(-1))
+            close(logp, d[f"{tag}/logp"].reshape(-1), 1e-5, 1e-6)
+            vals = torch.zeros(B, 1, device="cuda")
+            ops.mlp_forward(pc, dc, dev(d["share_obs"]), None, B, vals)
+            close(vals, d[f"{tag}/values"], 1e-5, 1e-6)
+
+
+def test_actor_act_sampling_distribution(ops):
+    """Sampling cannot match torch's CPU multinomial stream; check the distribution instead."""
+    torch.manual_seed(3)
+    D, A, B = 18, 5, 64
+    a = O.default_args()
+    net = O.ActorRef(a, D, A); _randomize(net, 5)
+    desc = ops.net_desc(D, A)
+    params, _, _ = _flat_from_module(ops, net, desc, "act.action_out.linear")
+    x = np.tile(np.random.default_rng(0).standard_normal((1, D)).astype(np.float32), (B, 1))
+    avail = np.ones((B, A), np.float32); avail[:, 2] = 0
+    with torch.no_grad():
+        feats, _ = net.features(torch.from_numpy(x[:1]), None, None)
+        z = net.act.logits(feats, torch.from_numpy(avail[:1]))
+        p = torch.softmax(z, -1).numpy()[0]
+    counts = np.zeros(A)
+    actions, logp = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    n_rounds = 400
+    for it in range(n_rounds):
+        ops.actor_act(params, desc, dev(x), dev(avail), B, False, 1234, it, actions, logp)
+        acts = actions.cpu().numpy().astype(int)
+        counts += np.bincount(acts, minlength=A)
+        lp = logp.cpu().numpy()
+        close(lp, np.log(p[acts]), 1e-5, 1e-5)
+    n = B * n_rounds
+    assert counts[2] == 0
+    mask = p > 0
+    chi2 = (((counts - n * p) ** 2)[mask] / (n * p[mask])).sum()
+    assert chi2 < 30.0, (chi2, counts / n, p)          # 3 dof, p ~ 1e-6
+    # same (seed, counter) -> same draw; different counter -> different stream
+    a1, a2 = torch.zeros(B, device="cuda"), torch.zeros(B, device="cuda")
+    ops.actor_act(params, desc, dev(x), dev(avail), B, False, 99, 5, a1, logp)
+    ops.actor_act(params, desc, dev(x), dev(avail), B, False, 99, 5, a2, logp)
+    np.testing.assert_array_equal(a1.cpu().numpy(), a2.cpu().numpy())
+
+
+@pytest.mark.parametrize("D,A,relu,LN,fn,B", NET_CASES)
+def test_mlp_backward_vs_autograd(ops, D, A, relu, LN, fn, B):
+    torch.manual_seed(D * 100 + A + 1)
+    a = O.default_args(use_ReLU=relu, layer_N=LN, use_feature_normalization=fn)
+    net = O.ActorRef(a, D, A) if A > 1 else O.CriticRef(a, D)
+    _randomize(net, 9)
+    head = "act.action_out.linear" if A > 1 else "v_out"
+    desc = ops.net_desc(D, A, LN, relu, fn)
+    params, layout, P = _flat_from_module(ops, net, desc, head)
+    rng = np.random.default_rng(B + 1)
+    n_rows = B + 17
+    x = rng.standard_normal((n_rows, D)).astype(np.float32) * 2
+    rows = rng.permutation(n_rows)[:B].astype(np.int32)
+    dout = (rng.standard_normal((B, A)) / np.sqrt(B)).astype(np.float32)
+    xt = torch.from_numpy(x[rows])
+    if A > 1:
+        feats, _ = net.features(xt, None, None)
+        out = net.act.action_out.linear(feats)
+    else:
+        out = net(xt, None, None)[0]
+    (out * torch.from_numpy(dout)).sum().backward()
+    ref = {k: p_.grad.numpy() for k, p_ in net.named_parameters() if p_.grad is not None}
+    n_slabs = ops.mlp_backward_slabs(B)
+    stride = ((P + 255) // 256) * 256 + 256
+    slabs = torch.full((n_slabs, stride), float("nan"), device="cuda")
+    ops.mlp_backward(params, desc, dev(x), dev(rows, torch.int32), B, dev(dout), slabs, stride, 256)
+    grad = torch.zeros(stride, device="cuda")
+    ops.slab_reduce(slabs[:, 256:].contiguous(), n_slabs, stride - 256, P, grad)
+    gflat = grad.cpu().numpy()
+    assert np.isfinite(gflat[:P]).all()
+    assert torch.isnan(slabs[:, :256]).all() and torch.isnan(slabs[:, 256 + P:]).all()    # wrote only its columns
+    from mappo_amd import flat
+    for key, off, shape in layout:
+        got = gflat[off: off + int(np.prod(shape))].reshape(shape)
+        close_rel_max(got, ref[key], 1e-4, f"grad {key} (D={D} A={A} B={B})")
+
+
+def test_mlp_full_size_linearity(ops):
+    """BASELINE config-2 size (76 800 rows): backward is linear in dout and matches a finite slab count."""
+    D, A, B = 54, 1, 76800
+    torch.manual_seed(0)
+    a = O.default_args()
+    net = O.CriticRef(a, D); _randomize(net, 2)
+    desc = ops.net_desc(D, A)
+    params, layout, P = _flat_from_module(ops, net, desc, "v_out")
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(B, D, device="cuda", generator=g)
+    d1 = torch.randn(B, 1, device="cuda", generator=g) / B
+    d2 = torch.randn(B, 1, device="cuda", generator=g) / B
+    n_slabs = ops.mlp_backward_slabs(B)
+    outs = []
+    for dd in (d1, d2, (d1 - 3 * d2).contiguous()):
+        slabs = torch.zeros(n_slabs, P, device="cuda")
+        ops.mlp_backward(params, desc, x, None, B, dd, slabs, P, 0)
+        grad = torch.zeros(P, device="cuda")
+        ops.slab_reduce(slabs, n_slabs, P, P, grad)
+        outs.append(grad)
+    close_rel_max(outs[2], (outs[0] - 3 * outs[1]).cpu().numpy(), 1e-4, "linearity")
+    # forward at full size vs the oracle on a strided subset
+    out = torch.zeros(B, 1, device="cuda")
+    ops.mlp_forward(params, desc, x, None, B, out)
+    idx = torch.arange(0, B, 97)
+    with torch.no_grad():
+        ref = net(x.cpu()[idx], None, None)[0].numpy()
+    close(out.cpu()[idx], ref, 1e-5, 2e-6)
+
+
+# ------------------------------------------------------------------------------------------------------
+def test_clip_adam_vs_oracle_and_torch(ops):
+    rng = np.random.default_rng(2)
+    Pa, Pc = 768, 1280
+    P = Pa + Pc
+    p0 = rng.standard_normal(P).astype(np.float32)
+    params = dev(p0)
+    m, v = torch.zeros(P, device="cuda"), torch.zeros(P, device="cuda")
+    hyper = torch.tensor([[7e-4, 0.9, 0.999, 1e-5, 0.0, 10.0, 1.0, 1.0], [5e-4, 0.9, 0.999, 1e-5, 0.0, 0.5, 1.0, 1.0]],
+                         dtype=torch.float32).cuda()
+    step = torch.zeros(2, dtype=torch.int32, device="cuda")
+    norms = torch.zeros(2, device="cuda")
+    ws = ops.optim_workspace(P, params.device)
+    ref_p = [p0[:Pa].astype(np.float64), p0[Pa:].astype(np.float64)]
+    ref_m = [np.zeros(Pa), np.zeros(Pc)]; ref_v = [np.zeros(Pa), np.zeros(Pc)]
+    tp = [torch.nn.Parameter(torch.from_numpy(p0[:Pa].copy())), torch.nn.Parameter(torch.from_numpy(p0[Pa:].copy()))]
+    topt = [torch.optim.Adam([tp[0]], lr=7e-4, eps=1e-5), torch.optim.Adam([tp[1]], lr=5e-4, eps=1e-5)]
+    for it in range(4):
+        gr = (rng.standard_normal(P) * (0.5 if it % 2 else 0.01)).astype(np.float32)
+        ops.clip_adam(params, dev(gr), m, v, [0, Pa, P], hyper, step, norms, ws)
+        for s, (lo, hi, lr, mx) in enumerate(((0, Pa, 7e-4, 10.0), (Pa, P, 5e-4, 0.5))):
+            ref_p[s], ref_m[s], ref_v[s], n = O.clip_adam_ref(ref_p[s], gr[lo:hi], ref_m[s], ref_v[s], it, lr, mx)
+            close(norms[s], n, 1e-6, 1e-9)
+            close(params[lo:hi], ref_p[s], 1e-6, 1e-7, f"params seg {s} it {it}")
+            tp[s].grad = torch.from_numpy(gr[lo:hi].copy())
+            torch.nn.utils.clip_grad_norm_([tp[s]], mx)
+            topt[s].step()
+            close(params[lo:hi], tp[s].detach().numpy(), 1e-6, 1e-7, f"torch seg {s} it {it}")
+    assert step.cpu().tolist() == [4, 4]
+    # a disabled segment (update_actor=False path) is left untouched
+    hyper[0, 7] = 0.0
+    before = params[:Pa].clone()
+    ops.clip_adam(params, dev(rng.standard_normal(P).astype(np.float32)), m, v, [0, Pa, P], hyper, step, norms, ws)
+    np.testing.assert_array_equal(before.cpu().numpy(), params[:Pa].cpu().numpy())
+    assert step.cpu().tolist() == [4, 5]
+
+
+def test_ops_reject_cpu_tensors(ops):
+    from mappo_amd._lib import MappoHipError
+    with pytest.raises(MappoHipError):
+        ops.adv_normalize(torch.zeros(8), torch.zeros(3, dtype=torch.float64))
