@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — agent-steps/sec of one full MAPPO iteration (collect + GAE + PPO) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one training iteration of BASELINE.json configs[1]: episode_length=25 rollout steps over
+n_rollout_threads=1024 (PER GPU: weak scaling, rollout threads shard across ranks) x 3 agents of MPE
+simple_spread-shaped synthetic observations (obs 18, share_obs 54, Discrete(5)) with the fused actor/critic
+kernels writing into the HBM replay buffer, the bootstrap value + GAE scan, ppo_epoch=10 x num_mini_batch=1
+PPO updates (forward, fused loss, backward, [RCCL all-reduce], clip + Adam) and after_update.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     : the fused PPO loss kernel (north_star's HBM-roofline kernel): algorithmic bytes 4*(3A+8) B/sample x
+                 samples per launch / mean launch duration measured with HIP events on its own stream.
+  cpu_baseline : the CPU oracle (a port of the reference's NumPy/torch-CPU path, oracle/mappo_oracle.py) timed on this
+                 box's host cores on a bounded sample of the same workload (rank 0, N == 1 only).
+  kernels      : mean device time of the other hot kernels from the same HIP-event hook (informative).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n_rollout_threads", type=int, default=1024, help="per GPU")
+    ap.add_argument("--episode_length", type=int, default=25)
+    ap.add_argument("--ppo_epoch", type=int, default=10)
+    ap.add_argument("--num_mini_batch", type=int, default=1)
+    ap.add_argument("--exact_minibatch_order", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_threads", type=int, default=0, help="0 = all cores of this box (max 16)")
+    return ap.parse_args()
+
+
+def make_args(ns):
+    from mappo_amd.config import get_config
+    a = get_config().parse_known_args([])[0]
+    a.algorithm_name = "mappo"
+    a.use_recurrent_policy = False
+    a.use_naive_recurrent_policy = False
+    a.env_name = "MPE"
+    a.episode_length = ns.episode_length
+    a.n_rollout_threads = ns.n_rollout_threads
+    a.ppo_epoch = ns.ppo_epoch
+    a.num_mini_batch = ns.num_mini_batch
+    a.lr = a.critic_lr = 7e-4                         # train_mpe_spread.sh:15-17
+    a.exact_minibatch_order = ns.exact_minibatch_order
+    a.seed = 1
+    return a
+
+
+class KernelTimer:
+    """Arms the C-side HIP-event hook (mappo_profile_arm) before calls of profiled ops.  Events are created
+    up front so that arming inside the timed region costs one ctypes call."""
+
+    def __init__(self):
+        self.active = set()
+        self.pool, self.used = [], {}
+
+    def reserve(self, n):
+        for _ in range(n):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); e.record()                      # forces creation of the hipEvent handles
+            self.pool.append((s, e))
+
+    def arm(self, ops, kernel):
+        if kernel not in self.active or not self.pool:
+            return
+        s, e = self.pool.pop()
+        ops.profile_arm(kernel, s, e)
+        self.used.setdefault(kernel, []).append((s, e))
+
+    def mean_us(self, kernel):
+        ps = self.used.get(kernel, [])
+        return 1e3 * sum(s.elapsed_time(e) for s, e in ps) / len(ps) if ps else None
+
+    def reset(self):
+        self.used = {}
+
+
+def install_timer(timer):
+    """Wrap the ops the trainer calls so that each call arms the hook for its dominant kernel."""
+    from mappo_amd import ops
+    for name, kernel in (("ppo_loss_fwd_bwd", "ppo_loss"), ("mlp_backward", "mlp_bwd"), ("mlp_forward", "mlp_fwd"),
+                         ("gae_scan", "gae"), ("clip_adam", "adam"), ("slab_reduce", "slab_reduce"), ("actor_act", "act")):
+        orig = getattr(ops, name)
+
+        def wrapped(*a, _orig=orig, _k=kernel, **kw):
+            timer.arm(ops, _k)
+            return _orig(*a, **kw)
+        setattr(ops, name, wrapped)
+
+
+def cpu_baseline(ns, n_threads):
+    """Oracle iteration on the host cores: same shapes / hyper-parameters / synthetic generator, bounded sample."""
+    from oracle import mappo_oracle as O
+    torch.set_num_threads(n_threads)
+    T, M, D, A = ns.episode_length, 3, 18, 5
+    oa = O.default_args(episode_length=T, n_rollout_threads=ns.n_rollout_threads, ppo_epoch=ns.ppo_epoch,
+                        num_mini_batch=ns.num_mini_batch, lr=7e-4, critic_lr=7e-4)
+    env = O.SyntheticMPEEnvRef(ns.n_rollout_threads, M, D, T, seed=1)
+    runner = O.RunnerRef(oa, env, M, D, D * M, A, seed=1)
+    runner.warmup()
+    # untimed warm-up on 2 of the 10 epochs' worth of work would still cost seconds; warm torch on a tiny twin instead
+    wa = O.default_args(episode_length=T, n_rollout_threads=8, ppo_epoch=2, lr=7e-4, critic_lr=7e-4)
+    w = O.RunnerRef(wa, O.SyntheticMPEEnvRef(8, M, D, T, seed=2), M, D, D * M, A, seed=2)
+    w.warmup(); w.run_iteration()
+    t0 = time.perf_counter()
+    _, timing = runner.run_iteration()
+    dt = time.perf_counter() - t0
+    steps = T * ns.n_rollout_threads * M
+    return dict(value=steps / dt, unit="agent-steps/s", cores=n_threads, kind="port",
+                sample=f"1 iteration (T={T} x N={ns.n_rollout_threads} x M={M} = {steps} agent-steps, ppo_epoch={ns.ppo_epoch}) "
+                       f"of the same workload, torch-CPU/NumPy oracle, {n_threads} threads; "
+                       f"collect {timing['collect']:.2f}s gae {timing['gae']:.3f}s train {timing['train']:.2f}s",
+                seconds=dt)
+
+
+def main():
+    ns = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    device = torch.device("cuda", torch.cuda.current_device())
+
+    from mappo_amd.envs.synthetic import SyntheticMPEEnv
+    from mappo_amd.runner.shared.mpe_runner import MPERunner
+    from mappo_amd.distributed import DataParallel
+
+    args = make_args(ns)
+    M, D, A = 3, 18, 5
+    torch.manual_seed(args.seed)                           # identical initial replicas on every rank
+    env = SyntheticMPEEnv(args.n_rollout_threads, M, D, A, args.episode_length, seed=1 + rank, device=device)
+    dp = DataParallel() if world > 1 else None
+    runner = MPERunner(dict(all_args=args, envs=env, eval_envs=None, num_agents=M, device=device, run_dir=None, dist_group=dp))
+    timer = KernelTimer()
+    install_timer(timer)
+    n_loss_launches = ns.steps * args.ppo_epoch * args.num_mini_batch
+    timer.reserve(n_loss_launches + 4 * (args.episode_length + 6 * args.ppo_epoch * args.num_mini_batch + 4))
+
+    runner.warmup()
+    for i in range(ns.warmup):
+        runner.run_episode(i, ns.warmup + ns.steps)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    timer.active = {"ppo_loss"}           # timed region: only the roofline kernel carries HIP events
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(ns.steps):
+        info, _ = runner.run_episode(ns.warmup + i, ns.warmup + ns.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    loss_us = timer.mean_us("ppo_loss")
+    # untimed extra pass: device time of the other hot kernels (informative)
+    timer.reset()
+    timer.active = {"mlp_bwd", "mlp_fwd", "gae", "adam", "slab_reduce", "act"}
+    runner.run_episode(0, 1)
+    torch.cuda.synchronize()
+    kern = {k: timer.mean_us(k) for k in sorted(timer.active) if timer.mean_us(k) is not None}
+    kern["ppo_loss"] = loss_us
+    timer.active = set()
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    per_gpu_steps = args.episode_length * args.n_rollout_threads * M
+    value = per_gpu_steps * world * ns.steps / dt
+    S = per_gpu_steps // args.num_mini_batch                 # samples per loss-kernel launch
+    bytes_per_sample = 4 * (3 * A + 8)                      # with available_actions (Discrete buffer)
+    roofline = None
+    if loss_us:
+        achieved = S * bytes_per_sample / (loss_us * 1e-6) / 1e9
+        roofline = dict(bound="hbm", kernel="ppo_loss_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_launch=S * bytes_per_sample,
+                        launch_us=loss_us)
+    out = dict(metric="agent-steps/sec (collect+GAE+PPO), MPE simple_spread 3-agent", value=value, unit="agent-steps/s",
+               n_gpus=world, steps=ns.steps, warmup=ns.warmup, ms_per_step=1e3 * dt / ns.steps, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="BASELINE configs[1]: MPE simple_spread shape, 3 agents, obs 18 / share_obs 54 / Discrete(5), "
+                                    f"n_rollout_threads={args.n_rollout_threads} per GPU, episode_length={args.episode_length}, "
+                                    f"MLP policy (mappo), ppo_epoch={args.ppo_epoch}, num_mini_batch={args.num_mini_batch}, lr 7e-4",
+                           n_rollout_threads_per_gpu=args.n_rollout_threads, episode_length=args.episode_length,
+                           num_agents=M, ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch,
+                           agent_steps_per_step=per_gpu_steps * world, parallelism=f"dp{world}",
+                           exact_minibatch_order=bool(args.exact_minibatch_order)),
+               roofline=roofline, kernels_us=kern,
+               last_train_info={k: float(v) for k, v in info.items()})
+    if rank == 0:
+        if world == 1 and not ns.no_cpu_baseline:
+            n_threads = ns.cpu_threads or min(os.cpu_count() or 1, 16)
+            try:
+                out["cpu_baseline"] = cpu_baseline(ns, n_threads)
+            except Exception as e:                             # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = dict(value=None, unit="agent-steps/s", cores=n_threads, kind="port", sample=f"failed: {e}")
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

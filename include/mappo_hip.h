@@ -151,6 +151,18 @@ int mappo_clip_adam(float *params, const float *grad, float *exp_avg, float *exp
                     const float *opt_hyper, int32_t *opt_step, float *grad_norms, void *workspace,
                     mappo_stream_t stream);
 
+/* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel is bracketed by the two
+ * hipEvent_t handles, recorded on the stream that launch uses; the hook disarms itself after one use. */
+#define MAPPO_PROF_GAE 0
+#define MAPPO_PROF_PPO_LOSS 1
+#define MAPPO_PROF_MLP_FWD 2
+#define MAPPO_PROF_MLP_BWD 3
+#define MAPPO_PROF_SLAB_REDUCE 4
+#define MAPPO_PROF_ADAM 5
+#define MAPPO_PROF_ACT 6
+#define MAPPO_PROF_COUNT 8
+int mappo_profile_arm(int32_t kernel_id, void *ev_start /*hipEvent_t*/, void *ev_stop /*hipEvent_t*/);
+
 /* ---- self test: fp32 MFMA operand/accumulator lane maps (used by tests/, not by the product path) --- */
 int mappo_selftest_mfma(const float *A /*[32][2]*/, const float *Bm /*[2][32]*/, float *D /*[32][32]*/,
                         mappo_stream_t stream);

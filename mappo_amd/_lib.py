@@ -2,6 +2,10 @@
 import ctypes as C
 import os
 
+import torch  # noqa: F401  — must come first: libmappo_hip.so has to bind to the HIP runtime torch already loaded
+#               (loading /opt/rocm's libamdhip64 before torch's own copy gives a process with two runtimes, and
+#               launches from the second one fail with "no ROCm-capable device is detected")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmappo_hip.so")
 
@@ -45,6 +49,7 @@ SIGNATURES = {
     "mappo_optim_workspace_bytes": (_I64, [_I64]),
     "mappo_slab_reduce": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
     "mappo_clip_adam": (C.c_int, [_P, _P, _P, _P, C.POINTER(_I64), _I32, _P, _P, _P, _P, _P]),
+    "mappo_profile_arm": (C.c_int, [_I32, _P, _P]),
     "mappo_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),
 }
 

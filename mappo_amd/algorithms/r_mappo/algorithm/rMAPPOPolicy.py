@@ -1,0 +1,146 @@
+"""R_MAPPOPolicy — API of `onpolicy/algorithms/r_mappo/algorithm/rMAPPOPolicy.py:6-127`.
+
+Owns ONE flat HBM buffer `[actor params | critic params]` (each padded to 256 floats) plus Adam moments,
+step counters and hyper-parameters on the device; `actor` / `critic` are nn.Module shells viewing it (same
+state_dict keys as the reference), `actor_optimizer` / `critic_optimizer` are facades over the fused
+clip+Adam kernel (mappo_clip_adam) that keep `param_groups[..]['lr']`, `state_dict()` and `zero_grad()`."""
+import torch
+
+from mappo_amd import flat as flat_layout
+from mappo_amd import ops
+from mappo_amd.utils.util import update_linear_schedule, to_device_f32
+from .r_actor_critic import R_Actor, R_Critic
+
+# opt_hyper row: lr, beta1, beta2, eps, weight_decay, max_grad_norm, use_clip, enabled
+H_LR, H_B1, H_B2, H_EPS, H_WD, H_MAXNORM, H_CLIP, H_ENABLED = range(8)
+
+
+class FlatAdam:
+    """torch.optim.Adam look-alike for one segment (actor or critic) of the policy's flat buffer."""
+
+    def __init__(self, policy, seg, lr, eps, weight_decay):
+        self._policy, self._seg = policy, seg
+        self.param_groups = [dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=weight_decay)]
+        self.sync_lr()
+
+    def sync_lr(self):
+        g = self.param_groups[0]
+        row = torch.tensor([g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"]], dtype=torch.float32)
+        self._policy.opt_hyper[self._seg, :5].copy_(row, non_blocking=True)
+
+    def zero_grad(self, set_to_none=True):
+        pass      # the fused backward overwrites every gradient slab; nothing accumulates between updates
+
+    def step(self):
+        raise RuntimeError("FlatAdam.step(): the Adam update is fused into R_MAPPO.ppo_update (mappo_clip_adam); "
+                           "there is no separate optimizer step and no autograd .grad to consume")
+
+    def _range(self):
+        b = self._policy.seg_bounds
+        return b[self._seg], b[self._seg + 1]
+
+    def state_dict(self):
+        lo, hi = self._range()
+        return dict(step=int(self._policy.opt_step[self._seg].item()), exp_avg=self._policy.exp_avg[lo:hi].clone(),
+                    exp_avg_sq=self._policy.exp_avg_sq[lo:hi].clone(), param_groups=[dict(g) for g in self.param_groups])
+
+    def load_state_dict(self, sd):
+        lo, hi = self._range()
+        self._policy.exp_avg[lo:hi].copy_(sd["exp_avg"])
+        self._policy.exp_avg_sq[lo:hi].copy_(sd["exp_avg_sq"])
+        self._policy.opt_step[self._seg] = int(sd["step"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+        self.sync_lr()
+
+
+class R_MAPPOPolicy:
+    def __init__(self, args, obs_space, cent_obs_space, act_space, device=torch.device("cuda")):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            from mappo_amd._lib import MappoHipError
+            raise MappoHipError("R_MAPPOPolicy needs a GPU device: the MAPPO hot path runs as HIP kernels on gfx950 and "
+                                "has no CPU fallback")
+        self.lr = args.lr
+        self.critic_lr = args.critic_lr
+        self.opti_eps = args.opti_eps
+        self.weight_decay = args.weight_decay
+        self.obs_space = obs_space
+        self.share_obs_space = cent_obs_space
+        self.act_space = act_space
+
+        # sizes first (descriptors only), then one allocation for both networks
+        from mappo_amd.utils.util import obs_dim_of
+        rec = bool(args.use_recurrent_policy or args.use_naive_recurrent_policy)
+        da = ops.net_desc(obs_dim_of(obs_space), act_space.n, args.layer_N, args.use_ReLU, args.use_feature_normalization,
+                          rec, args.hidden_size)
+        dc = ops.net_desc(obs_dim_of(cent_obs_space), 1, args.layer_N, args.use_ReLU, args.use_feature_normalization,
+                          rec, args.hidden_size)
+        _, pa = flat_layout.net_layout(da, "act.action_out.linear")
+        _, pc = flat_layout.net_layout(dc, "v_out")
+        pa_pad, pc_pad = flat_layout.padded(pa), flat_layout.padded(pc)
+        self.seg_bounds = [0, pa_pad, pa_pad + pc_pad]
+        self.n_flat = pa_pad + pc_pad
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.flat_params = torch.zeros(self.n_flat, **f32)
+        self.flat_grad = torch.zeros(self.n_flat, **f32)
+        self.exp_avg = torch.zeros(self.n_flat, **f32)
+        self.exp_avg_sq = torch.zeros(self.n_flat, **f32)
+        self.opt_step = torch.zeros(2, dtype=torch.int32, device=self.device)
+        self.opt_hyper = torch.zeros(2, 8, **f32)
+        self.opt_hyper[:, H_MAXNORM] = float(args.max_grad_norm)
+        self.opt_hyper[:, H_CLIP] = 1.0 if args.use_max_grad_norm else 0.0
+        self.opt_hyper[:, H_ENABLED] = 1.0
+        self.grad_norms = torch.zeros(2, **f32)
+        self.opt_workspace = ops.optim_workspace(self.n_flat, self.device)
+
+        self.actor = R_Actor(args, self.obs_space, self.act_space, self.device, flat=self.flat_params[:pa_pad])
+        self.critic = R_Critic(args, self.share_obs_space, self.device, flat=self.flat_params[pa_pad:])
+        self.actor_optimizer = FlatAdam(self, 0, self.lr, self.opti_eps, self.weight_decay)
+        self.critic_optimizer = FlatAdam(self, 1, self.critic_lr, self.opti_eps, self.weight_decay)
+
+    # rMAPPOPolicy.py:39-46
+    def lr_decay(self, episode, episodes):
+        update_linear_schedule(self.actor_optimizer, episode, episodes, self.lr)
+        update_linear_schedule(self.critic_optimizer, episode, episodes, self.critic_lr)
+
+    # rMAPPOPolicy.py:48-74
+    def get_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, masks, available_actions=None,
+                    deterministic=False):
+        actions, action_log_probs, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
+        values, rnn_states_critic = self.critic(cent_obs, rnn_states_critic, masks)
+        return values, actions, action_log_probs, rnn_states_actor, rnn_states_critic
+
+    # rMAPPOPolicy.py:76-86
+    def get_values(self, cent_obs, rnn_states_critic, masks):
+        values, _ = self.critic(cent_obs, rnn_states_critic, masks)
+        return values
+
+    # rMAPPOPolicy.py:88-114
+    def evaluate_actions(self, cent_obs, obs, rnn_states_actor, rnn_states_critic, action, masks, available_actions=None,
+                         active_masks=None):
+        action_log_probs, dist_entropy = self.actor.evaluate_actions(obs, rnn_states_actor, action, masks,
+                                                                     available_actions, active_masks)
+        values, _ = self.critic(cent_obs, rnn_states_critic, masks)
+        return values, action_log_probs, dist_entropy
+
+    # rMAPPOPolicy.py:116-127
+    def act(self, obs, rnn_states_actor, masks, available_actions=None, deterministic=False):
+        actions, _, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
+        return actions, rnn_states_actor
+
+    # ---- fused rollout step (K8 subsumes K1): outputs land in buffer slot `step` ------------------------------
+    @torch.no_grad()
+    def collect_into(self, buffer, step, use_available_actions=False, deterministic=False):
+        """get_actions on buffer slot `step` (mpe_runner.py:95-109 / smac_runner.py:110-125) with actions,
+        log-probs and values written straight into buffer.{actions, action_log_probs, value_preds}[step];
+        next rnn states (recurrent policies) go to slot step+1.  Returns the fp32 actions view [N, M, 1]."""
+        R = buffer.n_rollout_threads * buffer.num_agents
+        avail = buffer.available_actions[step].view(R, -1) if use_available_actions else None
+        out = (buffer.actions[step].view(R), buffer.action_log_probs[step].view(R))
+        masks = buffer.masks[step].view(R, 1)
+        _, _, rnn_a = self.actor(buffer.obs[step].view(R, -1), buffer.rnn_states[step].view(R, buffer.recurrent_N, -1),
+                                 masks, avail, deterministic, out=out)
+        _, rnn_c = self.critic(buffer.share_obs[step].view(R, -1),
+                               buffer.rnn_states_critic[step].view(R, buffer.recurrent_N, -1), masks,
+                               out=buffer.value_preds[step].view(R, 1))
+        return buffer.actions[step], rnn_a, rnn_c

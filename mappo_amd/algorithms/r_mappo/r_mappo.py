@@ -1,0 +1,222 @@
+"""R_MAPPO trainer — API of `onpolicy/algorithms/r_mappo/r_mappo.py:8-227`.
+
+`train(buffer)` keeps the reference's structure (advantage normalisation, ppo_epoch x num_mini_batch updates,
+six averaged statistics) but every update is a fixed sequence of HIP launches on the HBM-resident buffer:
+
+    minibatch moments -> ValueNorm update -> actor/critic forward (MFMA) -> fused PPO loss fwd+bwd ->
+    actor/critic backward (MFMA, forward recomputed) -> slab reduce -> [RCCL all-reduce] -> clip + Adam
+
+The minibatch is never materialised: kernels take int32 row indices into the buffer (or stream it in place
+when num_mini_batch == 1, where the permutation only reorders the terms of sums).  No `.item()` inside the
+loop (the reference syncs 3x per minibatch, r_mappo.py:207-209): statistics accumulate on the device and
+are read once at the end of train()."""
+import numpy as np
+import torch
+
+from mappo_amd import ops
+from mappo_amd.utils.util import to_device_f32
+from mappo_amd.utils.valuenorm import ValueNorm
+
+
+class R_MAPPO():
+    def __init__(self, args, policy, device=torch.device("cuda"), dist_group=None):
+        self.device = torch.device(device)
+        self.tpdv = dict(dtype=torch.float32, device=self.device)
+        self.policy = policy
+        self.args = args
+
+        self.clip_param = args.clip_param
+        self.ppo_epoch = args.ppo_epoch
+        self.num_mini_batch = args.num_mini_batch
+        self.data_chunk_length = args.data_chunk_length
+        self.value_loss_coef = args.value_loss_coef
+        self.entropy_coef = args.entropy_coef
+        self.max_grad_norm = args.max_grad_norm
+        self.huber_delta = args.huber_delta
+
+        self._use_recurrent_policy = args.use_recurrent_policy
+        self._use_naive_recurrent = args.use_naive_recurrent_policy
+        self._use_max_grad_norm = args.use_max_grad_norm
+        self._use_clipped_value_loss = args.use_clipped_value_loss
+        self._use_huber_loss = args.use_huber_loss
+        self._use_popart = args.use_popart
+        self._use_valuenorm = args.use_valuenorm
+        self._use_value_active_masks = args.use_value_active_masks
+        self._use_policy_active_masks = args.use_policy_active_masks
+        self._exact_order = bool(getattr(args, "exact_minibatch_order", False))
+
+        assert (self._use_popart and self._use_valuenorm) == False, \
+            "self._use_popart and self._use_valuenorm can not be set True simultaneously"
+        if self._use_popart:
+            raise NotImplementedError("use_popart: PopArt.update raises in the reference itself (SURVEY.md §8c)")
+        self.value_normalizer = ValueNorm(1, device=self.device) if self._use_valuenorm else None
+
+        self._cfg = ops.ppo_cfg(args)
+        self._dist = dist_group                      # mappo_amd.distributed.DataParallel or None
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self._mb_moments = torch.zeros(4, **f64)
+        self._adv_moments = torch.zeros(3, **f64)
+        self._stats = torch.zeros(6, **f64)
+        self._acc = torch.zeros(6, **f64)            # value_loss, policy_loss, dist_entropy, ratio, actor_gn, critic_gn
+        self._ws = {}
+        self._training = False
+
+    # ---- workspaces (allocated once per shape; nothing is allocated inside the update loop) -----------------
+    def _buf(self, name, shape, dtype=torch.float32, zero=False):
+        key = (name, tuple(shape), dtype)
+        t = self._ws.get(key)
+        if t is None:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self._ws[key] = t
+        return t
+
+    def _bytes(self, name, nbytes):
+        return self._buf(name, (int(nbytes),), torch.uint8)
+
+    # ---- one PPO update on rows of flat source arrays (r_mappo.py:91-164) -------------------------------------
+    def _update(self, src, rows, B, update_actor=True):
+        pol = self.policy
+        A = pol.actor.n_actions
+        lib = ops._lib.load()
+        vn_state = self.value_normalizer.state if self._use_valuenorm else None
+        # denominators of the masked means + the moments ValueNorm.update needs (cal_value_loss, r_mappo.py:65)
+        ops.minibatch_moments(src["returns"], src["active"], rows, B, self._mb_moments,
+                              self._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
+        if self._dist is not None:
+            self._dist.all_reduce_sum_(self._mb_moments)
+        if self._use_valuenorm:
+            ops.valuenorm_update(vn_state, self._mb_moments, self.value_normalizer.beta)
+        # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
+        logits = self._buf("logits", (B, A))
+        values = self._buf("values", (B,))
+        ops.mlp_forward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, logits)
+        ops.mlp_forward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, values)
+        # fused loss forward + backward
+        dlogits = self._buf("dlogits", (B, A))
+        dvalues = self._buf("dvalues", (B,))
+        ops.ppo_loss_fwd_bwd(logits, values, rows, src["avail"], src["actions"], src["old_logp"], src["adv"], src["active"],
+                             src["v_old"], src["returns"], vn_state, self._mb_moments, dlogits, dvalues, self._stats,
+                             self._cfg, self._bytes("loss_ws", lib.mappo_ppo_loss_workspace_bytes(B)))
+        # backward through both networks into per-workgroup slabs over the joint flat layout
+        n_slabs = ops.mlp_backward_slabs(B)
+        P = pol.n_flat
+        slabs = self._buf("slabs", (n_slabs, P), zero=True)
+        if update_actor:
+            ops.mlp_backward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, dlogits, slabs, P, 0)
+        elif not self._actor_slabs_clean:
+            slabs[:, :pol.seg_bounds[1]].zero_()
+        self._actor_slabs_clean = not update_actor
+        ops.mlp_backward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, dvalues, slabs, P, pol.seg_bounds[1])
+        ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
+        if self._dist is not None:
+            self._dist.all_reduce_sum_(pol.flat_grad)          # C1: one flat fp32 all-reduce per minibatch
+        if update_actor != self._actor_enabled:                  # torch >= 2: grad None => Adam skips the actor
+            pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
+            self._actor_enabled = update_actor
+        ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper,
+                      pol.opt_step, pol.grad_norms, pol.opt_workspace)
+        self._acc[:4].add_(self._stats[:4])
+        self._acc[4:].add_(pol.grad_norms)
+
+    _actor_slabs_clean = True
+    _actor_enabled = True
+
+    def _buffer_sources(self, buffer, adv):
+        T = buffer.episode_length
+        R = buffer.n_rollout_threads * buffer.num_agents
+        S = T * R
+        flat = lambda a: a[:T].view(S, -1)
+        return dict(obs=flat(buffer.obs), share_obs=flat(buffer.share_obs),
+                    avail=flat(buffer.available_actions) if buffer.available_actions is not None else None,
+                    actions=buffer.actions.view(S), old_logp=buffer.action_log_probs.view(S), adv=adv,
+                    active=buffer.active_masks[:T].view(S), v_old=buffer.value_preds[:T].view(S),
+                    returns=buffer.returns[:T].view(S)), S
+
+    # ---- r_mappo.py:166-219 ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def train(self, buffer, update_actor=True):
+        if self._use_recurrent_policy or self._use_naive_recurrent:
+            from mappo_amd.recurrent import train_recurrent
+            return train_recurrent(self, buffer, update_actor)
+        T = buffer.episode_length
+        S = T * buffer.n_rollout_threads * buffer.num_agents
+        adv = self.compute_advantages(buffer)
+        src, _ = self._buffer_sources(buffer, adv)
+        self._acc.zero_()
+        for _ in range(self.ppo_epoch):
+            if self.num_mini_batch == 1 and not self._exact_order:
+                batches = [(None, S)]                      # whole buffer in place (see module docstring)
+            else:
+                batches = [(rows, rows.numel()) for rows in buffer.feed_forward_rows(self.num_mini_batch)]
+            for rows, B in batches:
+                self._update(src, rows, B, update_actor)
+        return self._finish_train_info()
+
+    def compute_advantages(self, buffer):
+        """r_mappo.py:174-182 as two kernels around an (optional) 3-double all-reduce."""
+        T = buffer.episode_length
+        S = T * buffer.n_rollout_threads * buffer.num_agents
+        adv = self._buf("adv", (S,))
+        lib = ops._lib.load()
+        vn_state = self.value_normalizer.state if self._use_valuenorm else None
+        ops.adv_moments(buffer.returns[:T].view(S), buffer.value_preds[:T].view(S), buffer.active_masks[:T].view(S), vn_state,
+                        adv, self._adv_moments, self._bytes("adv_ws", lib.mappo_adv_workspace_bytes(S)))
+        if self._dist is not None:
+            self._dist.all_reduce_sum_(self._adv_moments)
+        ops.adv_normalize(adv, self._adv_moments)
+        return adv
+
+    def _finish_train_info(self):
+        num_updates = self.ppo_epoch * self.num_mini_batch
+        if self._dist is not None:
+            self._dist.all_reduce_sum_(self._acc[:4])          # local numerators / global denominators -> global stats
+        acc = (self._acc / max(num_updates, 1)).cpu().numpy()    # the only host sync of train()
+        return dict(value_loss=float(acc[0]), policy_loss=float(acc[1]), dist_entropy=float(acc[2]),
+                    actor_grad_norm=float(acc[4]), critic_grad_norm=float(acc[5]), ratio=float(acc[3]))
+
+    # ---- r_mappo.py:91-164 with an explicit (already gathered) sample tuple ---------------------------------
+    @torch.no_grad()
+    def ppo_update(self, sample, update_actor=True):
+        if self._use_recurrent_policy or self._use_naive_recurrent:
+            from mappo_amd.recurrent import ppo_update_recurrent
+            return ppo_update_recurrent(self, sample, update_actor)
+        (share_obs, obs, rnn_a, rnn_c, actions, v_old, ret, masks, active, old_logp, adv, avail) = sample
+        d = lambda x: to_device_f32(x, self.device)
+        B = np.shape(obs)[0] if not torch.is_tensor(obs) else obs.shape[0]
+        src = dict(obs=d(obs), share_obs=d(share_obs), avail=d(avail) if avail is not None else None,
+                   actions=d(actions).view(B), old_logp=d(old_logp).view(B), adv=d(adv).view(B), active=d(active).view(B),
+                   v_old=d(v_old).view(B), returns=d(ret).view(B))
+        self._acc.zero_()
+        self._update(src, None, B, update_actor)
+        a = self._acc.cpu().numpy()
+        # value_loss, critic_grad_norm, policy_loss, dist_entropy, actor_grad_norm, imp_weights (mean here)
+        return a[0], a[5], a[1], a[2], a[4], a[3]
+
+    # ---- r_mappo.py:52-89 (API completeness; train() uses the fused kernel instead) --------------------------
+    @torch.no_grad()
+    def cal_value_loss(self, values, value_preds_batch, return_batch, active_masks_batch):
+        d = lambda x: to_device_f32(x, self.device)
+        values, value_preds_batch, return_batch, active_masks_batch = d(values), d(value_preds_batch), d(return_batch), d(active_masks_batch)
+        clipped = value_preds_batch + (values - value_preds_batch).clamp(-self.clip_param, self.clip_param)
+        if self._use_valuenorm:
+            self.value_normalizer.update(return_batch)
+            tgt = self.value_normalizer.normalize(return_batch)
+        else:
+            tgt = return_batch
+        e_c, e_o = tgt - clipped, tgt - values
+
+        def loss(e):
+            if self._use_huber_loss:
+                dl = self.huber_delta
+                return torch.where(e.abs() <= dl, e * e / 2, dl * (e.abs() - dl / 2))
+            return e * e / 2
+        l = torch.max(loss(e_o), loss(e_c)) if self._use_clipped_value_loss else loss(e_o)
+        if self._use_value_active_masks:
+            return (l * active_masks_batch).sum() / active_masks_batch.sum()
+        return l.mean()
+
+    def prep_training(self):
+        self._training = True
+
+    def prep_rollout(self):
+        self._training = False

@@ -30,6 +30,18 @@ void mappo_set_error(const char *fmt, ...);
 
 static inline hipStream_t as_stream(mappo_stream_t s) { return (hipStream_t)s; }
 
+// ---- one-shot HIP-event bracket around the dominant kernel of an entry point (mappo_profile_arm) ----------
+struct ProfSlot { hipEvent_t start, stop; };
+extern ProfSlot g_prof[MAPPO_PROF_COUNT];
+#define PROF_BEGIN(id, st) do { if (g_prof[id].start) (void)hipEventRecord(g_prof[id].start, st); } while (0)
+#define PROF_END(id, st)                                                     \
+  do {                                                                       \
+    if (g_prof[id].stop) {                                                   \
+      (void)hipEventRecord(g_prof[id].stop, st);                             \
+      g_prof[id].start = g_prof[id].stop = nullptr;                          \
+    }                                                                        \
+  } while (0)
+
 // ---- ValueNorm statistics from the 3-float state (valuenorm.py:31-35), fp32 like torch ------------
 struct VnStats {
   float mean, sd;  // sd = sqrt(var)

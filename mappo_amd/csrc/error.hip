@@ -13,3 +13,12 @@ void mappo_set_error(const char *fmt, ...) {
 
 extern "C" const char *mappo_last_error(void) { return g_err; }
 extern "C" int mappo_abi_version(void) { return 1; }
+
+ProfSlot g_prof[MAPPO_PROF_COUNT] = {};
+
+extern "C" int mappo_profile_arm(int32_t kernel_id, void *ev_start, void *ev_stop) {
+  MAPPO_REQUIRE(kernel_id >= 0 && kernel_id < MAPPO_PROF_COUNT, "profile_arm: kernel_id %d", kernel_id);
+  g_prof[kernel_id].start = (hipEvent_t)ev_start;
+  g_prof[kernel_id].stop = (hipEvent_t)ev_stop;
+  return MAPPO_OK;
+}

@@ -776,9 +776,12 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
     hipLaunchKernelGGL((mlp_forward_kernel<R, L, MODE>), grid, block, lds_bytes, st, a);                        \
   } while (0)
   const bool relu = a.desc.use_relu != 0;
+  const int prof_id = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
+  PROF_BEGIN(prof_id, st);
   if (LN == 0) { if (relu) FWD(true, 0); else FWD(false, 0); }
   else if (LN == 1) { if (relu) FWD(true, 1); else FWD(false, 1); }
   else { if (relu) FWD(true, 2); else FWD(false, 2); }
+  PROF_END(prof_id, st);
 #undef FWD
   MAPPO_CHECK_LAUNCH(who);
   return MAPPO_OK;
@@ -847,9 +850,11 @@ extern "C" int mappo_mlp_backward(const float *params, const mappo_net_desc *des
     hipLaunchKernelGGL((mlp_backward_kernel<R, L>), grid, block, lds_bytes, st, a);                         \
   } while (0)
   const bool relu = desc->use_relu != 0;
+  PROF_BEGIN(MAPPO_PROF_MLP_BWD, st);
   if (LN == 0) { if (relu) BWD(true, 0); else BWD(false, 0); }
   else if (LN == 1) { if (relu) BWD(true, 1); else BWD(false, 1); }
   else { if (relu) BWD(true, 2); else BWD(false, 2); }
+  PROF_END(MAPPO_PROF_MLP_BWD, st);
 #undef BWD
   MAPPO_CHECK_LAUNCH("mlp_backward");
   return MAPPO_OK;

@@ -112,8 +112,10 @@ extern "C" int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t sl
                                  mappo_stream_t stream) {
   MAPPO_REQUIRE(slabs && grad && n_slabs > 0 && P > 0 && slab_stride >= P, "slab_reduce: bad arguments");
   const int nblk = (int)((P + OPT_BLOCK - 1) / OPT_BLOCK);
+  PROF_BEGIN(MAPPO_PROF_SLAB_REDUCE, as_stream(stream));
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, as_stream(stream), slabs, (int)n_slabs,
                      slab_stride, P, grad);
+  PROF_END(MAPPO_PROF_SLAB_REDUCE, as_stream(stream));
   MAPPO_CHECK_LAUNCH("slab_reduce");
   return MAPPO_OK;
 }
@@ -137,11 +139,13 @@ extern "C" int mappo_clip_adam(float *params, const float *grad, float *exp_avg,
   double *partials = (double *)workspace;
   float *seg_ws = (float *)((char *)workspace + (((size_t)nblk * sizeof(double) + 63) / 64) * 64);
   hipStream_t st = as_stream(stream);
+  PROF_BEGIN(MAPPO_PROF_ADAM, st);
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, grad, P, partials);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(OPT_BLOCK), 0, st, (const double *)partials, sb, opt_hyper,
                      opt_step, grad_norms, seg_ws);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, params, grad, exp_avg, exp_avg_sq, sb, opt_hyper,
                      (const float *)seg_ws);
+  PROF_END(MAPPO_PROF_ADAM, st);
   MAPPO_CHECK_LAUNCH("clip_adam");
   return MAPPO_OK;
 }

@@ -34,8 +34,9 @@ __global__ __launch_bounds__(PL_BLOCK) void ppo_loss_kernel(PlArgs p) {
   const int A = p.A;
   const int tid = threadIdx.x;
   const VnStats vn = vn_stats(p.cfg.use_valuenorm ? p.vn_state : nullptr);
+  // denominators come from mb_moments (global over all ranks in a data-parallel run), not from the local B
   const double sum_active = p.mb_moments[2];
-  const float inv_B = (float)(1.0 / (double)p.B);
+  const float inv_B = (float)(1.0 / (p.mb_moments[3] > 0.0 ? p.mb_moments[3] : 1.0));
   const float inv_act = (float)(1.0 / (sum_active > 0.0 ? sum_active : 1.0));
   const float scale_pi = p.cfg.use_policy_active_masks ? inv_act : inv_B;
   const float scale_v = p.cfg.use_value_active_masks ? inv_act : inv_B;
@@ -169,15 +170,18 @@ __global__ __launch_bounds__(PL_BLOCK) void ppo_stats_kernel(const double *__res
   }
   block_sum<4>(v, smem);
   if (threadIdx.x == 0) {
+    // local numerators over GLOBAL denominators: summing stats[0..3] over data-parallel ranks gives the
+    // single-process value
     const double sa = mb_moments[2] > 0.0 ? mb_moments[2] : 1.0;
-    const double den_pi = use_policy_active ? sa : (double)B;
-    const double den_v = use_value_active ? sa : (double)B;
+    const double Bg = mb_moments[3] > 0.0 ? mb_moments[3] : 1.0;
+    const double den_pi = use_policy_active ? sa : Bg;
+    const double den_v = use_value_active ? sa : Bg;
     stats[0] = v[2] / den_v;        // value_loss
     stats[1] = -v[0] / den_pi;      // policy_loss
     stats[2] = v[1] / den_pi;       // dist_entropy
-    stats[3] = v[3] / (double)B;    // imp_weights.mean()
+    stats[3] = v[3] / Bg;           // imp_weights.mean()
     stats[4] = mb_moments[2];
-    stats[5] = (double)B;
+    stats[5] = mb_moments[3];
   }
 }
 
@@ -206,7 +210,9 @@ extern "C" int mappo_ppo_loss_fwd_bwd(const float *logits, const float *values, 
   p.dlogits = dlogits; p.dvalues = dvalues; p.partials = (double *)workspace; p.cfg = *cfg; p.B = B; p.A = A;
   const int nblk = pl_blocks(B);
   const size_t lds = (size_t)PL_BLOCK * A * sizeof(float);
+  PROF_BEGIN(MAPPO_PROF_PPO_LOSS, as_stream(stream));
   hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(PL_BLOCK), lds, as_stream(stream), p);
+  PROF_END(MAPPO_PROF_PPO_LOSS, as_stream(stream));
   hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(PL_BLOCK), 0, as_stream(stream), (const double *)workspace, nblk,
                      mb_moments, B, cfg->use_policy_active_masks, cfg->use_value_active_masks, stats);
   MAPPO_CHECK_LAUNCH("ppo_loss_fwd_bwd");

@@ -155,3 +155,17 @@ def clip_adam(params, grad, exp_avg, exp_avg_sq, seg_bounds, opt_hyper, opt_step
 def selftest_mfma(A, Bm, D):
     rc = _lib.load().mappo_selftest_mfma(_ptr(A), _ptr(Bm), _ptr(D), _stream())
     _lib.check(rc, "mappo_selftest_mfma")
+
+
+# ---- measurement hook -----------------------------------------------------------------------------
+PROF_IDS = dict(gae=0, ppo_loss=1, mlp_fwd=2, mlp_bwd=3, slab_reduce=4, adam=5, act=6)
+
+
+def profile_arm(kernel, start_event, stop_event):
+    """Bracket the next launch of `kernel`'s dominant HIP kernel with two torch.cuda.Event(enable_timing=True)
+    (recorded by the C side on the stream that launch uses).  One-shot."""
+    for ev in (start_event, stop_event):
+        if ev.cuda_event == 0:                 # torch creates the hipEvent lazily on first record
+            ev.record()
+    rc = _lib.load().mappo_profile_arm(PROF_IDS[kernel], C.c_void_p(start_event.cuda_event), C.c_void_p(stop_event.cuda_event))
+    _lib.check(rc, "mappo_profile_arm")

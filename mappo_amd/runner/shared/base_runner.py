@@ -1,0 +1,158 @@
+"""Runner base — API of `onpolicy/runner/shared/base_runner.py:12-171`.
+
+Same `config` dict (`all_args, envs, eval_envs, num_agents, device, run_dir[, render_envs]`), same attribute
+names and the same `compute / train / save / restore / log_*` methods.  Differences, all on purpose:
+  * wandb / tensorboardX are optional (absent in this image): without them scalars go to `<run_dir>/logs/scalars.jsonl`;
+  * `restore()` runs after the trainer exists (the reference calls it before and hits AttributeError);
+  * checkpoints are loaded with `weights_only=True`."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from mappo_amd.utils.shared_buffer import SharedReplayBuffer
+
+
+def _t2n(x):
+    return x.detach().cpu().numpy()
+
+
+class _JsonlWriter:
+    def __init__(self, log_dir):
+        self.path = os.path.join(log_dir, "scalars.jsonl")
+
+    def add_scalars(self, tag, values, step):
+        with open(self.path, "a") as f:
+            f.write(json.dumps({"tag": tag, "step": int(step), **{k: float(v) for k, v in values.items()}}) + "\n")
+
+
+class Runner(object):
+    def __init__(self, config):
+        self.all_args = config["all_args"]
+        self.envs = config["envs"]
+        self.eval_envs = config.get("eval_envs")
+        self.device = config["device"]
+        self.num_agents = config["num_agents"]
+        if "render_envs" in config:
+            self.render_envs = config["render_envs"]
+        a = self.all_args
+        g = lambda name, default=None: getattr(a, name, default)
+        self.env_name = g("env_name", "MPE")
+        self.algorithm_name = g("algorithm_name", "mappo")
+        self.experiment_name = g("experiment_name", "check")
+        self.use_centralized_V = g("use_centralized_V", True)
+        self.use_obs_instead_of_state = g("use_obs_instead_of_state", False)
+        self.num_env_steps = g("num_env_steps", 10e6)
+        self.episode_length = a.episode_length
+        self.n_rollout_threads = a.n_rollout_threads
+        self.n_eval_rollout_threads = g("n_eval_rollout_threads", 1)
+        self.n_render_rollout_threads = g("n_render_rollout_threads", 1)
+        self.use_linear_lr_decay = g("use_linear_lr_decay", False)
+        self.hidden_size = a.hidden_size
+        self.use_wandb = g("use_wandb", False)
+        self.use_render = g("use_render", False)
+        self.recurrent_N = a.recurrent_N
+        self.save_interval = g("save_interval", 1)
+        self.use_eval = g("use_eval", False)
+        self.eval_interval = g("eval_interval", 25)
+        self.log_interval = g("log_interval", 5)
+        self.model_dir = g("model_dir", None)
+
+        self.writter = None
+        self.run_dir = config.get("run_dir")
+        self.save_dir = None
+        wandb = None
+        if self.use_wandb:
+            try:
+                import wandb          # noqa: F401  (optional)
+            except ImportError:
+                wandb, self.use_wandb = None, False
+        if self.use_wandb:
+            self.save_dir = self.run_dir = str(wandb.run.dir)
+        elif self.run_dir is not None:
+            self.log_dir = os.path.join(str(self.run_dir), "logs")
+            os.makedirs(self.log_dir, exist_ok=True)
+            try:
+                from tensorboardX import SummaryWriter
+                self.writter = SummaryWriter(self.log_dir)
+            except ImportError:
+                self.writter = _JsonlWriter(self.log_dir)
+            self.save_dir = os.path.join(str(self.run_dir), "models")
+            os.makedirs(self.save_dir, exist_ok=True)
+
+        from mappo_amd.algorithms.r_mappo.r_mappo import R_MAPPO as TrainAlgo
+        from mappo_amd.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy as Policy
+
+        share_observation_space = self.envs.share_observation_space[0] if self.use_centralized_V else self.envs.observation_space[0]
+        self.policy = Policy(self.all_args, self.envs.observation_space[0], share_observation_space,
+                             self.envs.action_space[0], device=self.device)
+        self.trainer = TrainAlgo(self.all_args, self.policy, device=self.device, dist_group=config.get("dist_group"))
+        if self.model_dir is not None:
+            self.restore()
+        self.buffer = SharedReplayBuffer(self.all_args, self.num_agents, self.envs.observation_space[0],
+                                         share_observation_space, self.envs.action_space[0], device=self.device)
+
+    def run(self):
+        raise NotImplementedError
+
+    def warmup(self):
+        raise NotImplementedError
+
+    def collect(self, step):
+        raise NotImplementedError
+
+    def insert(self, data):
+        raise NotImplementedError
+
+    # base_runner.py:110-118
+    @torch.no_grad()
+    def compute(self):
+        self.trainer.prep_rollout()
+        b = self.buffer
+        R = b.n_rollout_threads * b.num_agents
+        next_values = self.trainer.policy.get_values(b.share_obs[-1].view(R, -1), b.rnn_states_critic[-1].view(R, b.recurrent_N, -1),
+                                                     b.masks[-1].view(R, 1))
+        b.compute_returns(next_values, self.trainer.value_normalizer)
+
+    # base_runner.py:120-125
+    def train(self):
+        self.trainer.prep_training()
+        train_infos = self.trainer.train(self.buffer)
+        self.buffer.after_update()
+        return train_infos
+
+    # base_runner.py:127-135
+    def save(self):
+        if self.save_dir is None:
+            return
+        torch.save(self.trainer.policy.actor.state_dict(), os.path.join(self.save_dir, "actor.pt"))
+        torch.save(self.trainer.policy.critic.state_dict(), os.path.join(self.save_dir, "critic.pt"))
+        if self.trainer._use_valuenorm:
+            torch.save(self.trainer.value_normalizer.state_dict(), os.path.join(self.save_dir, "vnorm.pt"))
+
+    # base_runner.py:137-146
+    def restore(self):
+        load = lambda name: torch.load(os.path.join(str(self.model_dir), name), map_location=self.device, weights_only=True)
+        self.policy.actor.load_state_dict(load("actor.pt"))
+        if not self.use_render:
+            self.policy.critic.load_state_dict(load("critic.pt"))
+            if self.trainer._use_valuenorm:
+                self.trainer.value_normalizer.load_state_dict(load("vnorm.pt"))
+
+    def log_train(self, train_infos, total_num_steps):
+        for k, v in train_infos.items():
+            if self.use_wandb:
+                import wandb
+                wandb.log({k: v}, step=total_num_steps)
+            elif self.writter is not None:
+                self.writter.add_scalars(k, {k: v}, total_num_steps)
+
+    def log_env(self, env_infos, total_num_steps):
+        for k, v in env_infos.items():
+            if len(v) > 0:
+                if self.use_wandb:
+                    import wandb
+                    wandb.log({k: np.mean(v)}, step=total_num_steps)
+                elif self.writter is not None:
+                    self.writter.add_scalars(k, {k: np.mean(v)}, total_num_steps)

@@ -1,0 +1,132 @@
+"""MPERunner — API of `onpolicy/runner/shared/mpe_runner.py:11-183` (training loop, warmup, collect, insert, eval).
+
+The rollout step is fused: `collect` runs the actor (sampling + log-prob) and critic kernels on buffer slot
+`step` and their outputs land directly in `buffer.{actions, action_log_probs, value_preds}[step]`
+(R_MAPPOPolicy.collect_into); `insert` only stores what the environment produced.  Nothing crosses PCIe when
+the vec-env yields device tensors (mappo_amd.envs.synthetic); NumPy-returning envs (the reference's
+Dummy/SubprocVecEnv) work too — their arrays are uploaded by the buffer."""
+import time
+
+import numpy as np
+import torch
+
+from .base_runner import Runner, _t2n
+
+
+class MPERunner(Runner):
+    def __init__(self, config):
+        super(MPERunner, self).__init__(config)
+        self._onehot = None
+
+    def run(self):
+        self.warmup()
+        start = time.time()
+        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads
+        for episode in range(episodes):
+            train_infos, infos = self.run_episode(episode, episodes)
+            total_num_steps = (episode + 1) * self.episode_length * self.n_rollout_threads
+            if episode % self.save_interval == 0 or episode == episodes - 1:
+                self.save()
+            if episode % self.log_interval == 0:
+                end = time.time()
+                print("\n Scenario {} Algo {} Exp {} updates {}/{} episodes, total num timesteps {}/{}, FPS {}.\n".format(
+                    getattr(self.all_args, "scenario_name", "synthetic"), self.algorithm_name, self.experiment_name,
+                    episode, episodes, total_num_steps, self.num_env_steps, int(total_num_steps / (end - start))))
+                env_infos = {}
+                if self.env_name == "MPE" and infos is not None:
+                    for agent_id in range(self.num_agents):
+                        idv_rews = [info[agent_id]["individual_reward"] for info in infos
+                                    if "individual_reward" in info[agent_id].keys()]
+                        env_infos["agent%i/individual_rewards" % agent_id] = idv_rews
+                train_infos["average_episode_rewards"] = float(self.buffer.rewards.mean().item()) * self.episode_length
+                print("average episode rewards is {}".format(train_infos["average_episode_rewards"]))
+                self.log_train(train_infos, total_num_steps)
+                self.log_env(env_infos, total_num_steps)
+            if episode % self.eval_interval == 0 and self.use_eval:
+                self.eval(total_num_steps)
+
+    def run_episode(self, episode=0, episodes=1):
+        """One iteration of the hot loop (mpe_runner.py:22-40): T x (collect, env.step, insert), compute, train."""
+        if self.use_linear_lr_decay:
+            self.trainer.policy.lr_decay(episode, episodes)
+        infos = None
+        for step in range(self.episode_length):
+            values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env = self.collect(step)
+            obs, rewards, dones, infos = self.envs.step(actions_env)
+            data = obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic
+            self.insert(data)
+        self.compute()
+        return self.train(), infos
+
+    # mpe_runner.py:81-93
+    def warmup(self):
+        obs = self.envs.reset()
+        b = self.buffer
+        obs_t = torch.as_tensor(obs, dtype=torch.float32).to(b.device)
+        b.obs[0].copy_(obs_t)
+        b.share_obs[0].copy_(self._share_obs(obs_t))
+
+    def _share_obs(self, obs_t):
+        if self.use_centralized_V:                      # mpe_runner.py:133-135: all agents' obs, repeated per agent
+            N = obs_t.shape[0]
+            return obs_t.reshape(N, 1, -1).expand(N, self.num_agents, -1)
+        return obs_t
+
+    # mpe_runner.py:95-123
+    @torch.no_grad()
+    def collect(self, step):
+        self.trainer.prep_rollout()
+        b = self.buffer
+        actions, rnn_states, rnn_states_critic = self.trainer.policy.collect_into(b, step)
+        if self._onehot is None:
+            self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
+        needs_host = getattr(self.envs, "needs_host_actions", False)
+        actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]   # np.eye(n)[actions]
+        if needs_host:
+            actions_env = _t2n(actions_env)
+        return b.value_preds[step], actions, b.action_log_probs[step], rnn_states, rnn_states_critic, actions_env
+
+    # mpe_runner.py:125-139
+    def insert(self, data):
+        obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic = data
+        b = self.buffer
+        dev = b.device
+        obs_t = torch.as_tensor(obs, dtype=torch.float32).to(dev)
+        dones_t = torch.as_tensor(dones).to(dev)
+        masks = (~dones_t).to(torch.float32).view(b.n_rollout_threads, b.num_agents, 1)
+        rnn_a = rnn_c = None
+        if self.trainer._use_recurrent_policy or self.trainer._use_naive_recurrent:
+            keep = masks.view(b.n_rollout_threads, b.num_agents, 1, 1)
+            rnn_a = rnn_states.view(b.n_rollout_threads, b.num_agents, b.recurrent_N, -1) * keep
+            rnn_c = rnn_states_critic.view(b.n_rollout_threads, b.num_agents, b.recurrent_N, -1) * keep
+        b.insert_env(self._share_obs(obs_t), obs_t, rewards, masks, rnn_a, rnn_c)
+
+    @torch.no_grad()
+    def eval(self, total_num_steps):
+        """mpe_runner.py:141-183: deterministic `act` on the eval envs, average episode reward."""
+        envs = self.eval_envs
+        if envs is None:
+            return
+        eval_episode_rewards = []
+        obs = torch.as_tensor(envs.reset(), dtype=torch.float32).to(self.device)
+        N = obs.shape[0]
+        R = N * self.num_agents
+        rnn_states = torch.zeros(R, self.recurrent_N, self.hidden_size, device=self.device)
+        masks = torch.ones(R, 1, device=self.device)
+        eye = torch.eye(envs.action_space[0].n, device=self.device)
+        for _ in range(self.episode_length):
+            self.trainer.prep_rollout()
+            action, rnn_states = self.trainer.policy.act(obs.reshape(R, -1), rnn_states, masks, deterministic=True)
+            actions_env = eye[action.view(N, self.num_agents)]
+            if getattr(envs, "needs_host_actions", False):
+                actions_env = _t2n(actions_env)
+            obs, rewards, dones, _ = envs.step(actions_env)
+            obs = torch.as_tensor(obs, dtype=torch.float32).to(self.device)
+            dones_t = torch.as_tensor(dones).to(self.device).view(R)
+            eval_episode_rewards.append(torch.as_tensor(rewards, dtype=torch.float32).to(self.device))
+            rnn_states = rnn_states * (~dones_t).view(R, 1, 1)
+            masks = (~dones_t).to(torch.float32).view(R, 1)
+        rew = torch.stack(eval_episode_rewards)
+        info = {"eval_average_episode_rewards": [float(rew.sum(0).mean().item())]}
+        print("eval average episode rewards of agent: " + str(info["eval_average_episode_rewards"][0]))
+        self.log_env(info, total_num_steps)
