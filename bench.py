@@ -10,8 +10,11 @@ kernels writing into the HBM replay buffer, the bootstrap value + GAE scan, ppo_
 PPO updates (forward, fused loss, backward, [RCCL all-reduce], clip + Adam) and after_update.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     : the fused PPO loss kernel (north_star's HBM-roofline kernel): algorithmic bytes 4*(3A+8) B/sample x
-                 samples per launch / mean launch duration measured with HIP events on its own stream.
+  roofline     : the dominant kernel of the step — mlp_update_kernel (critic): forward + value loss + backward of the
+                 critic MLP in one launch, bound by the fp32 MFMA rate; algorithmic flops 6*MACs/sample (forward, dW, dX —
+                 the in-kernel forward recompute is NOT counted) / launch duration from HIP events attached to the dispatch.
+  ppo_loss_roofline : the standalone fused PPO loss kernel (mappo_ppo_loss_fwd_bwd, north_star's HBM-roofline kernel)
+                 on this step's buffer and at BASELINE configs[4] size: 4*(3A+8) B/sample / launch duration.
   cpu_baseline : the CPU oracle (a port of the reference's NumPy/torch-CPU path, oracle/mappo_oracle.py) timed on this
                  box's host cores on a bounded sample of the same workload (rank 0, N == 1 only).
   kernels      : mean device time of the other hot kernels from the same HIP-event hook (informative).
@@ -28,6 +31,48 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+
+
+def ppo_loss_roofline(runner, timer, A):
+    """The standalone fused PPO loss kernel (mappo_ppo_loss_fwd_bwd) with HIP events attached to its dispatch:
+    (a) on this run's replay buffer (one launch over the whole buffer, as --unfused_update issues it),
+    (b) on synthetic inputs of BASELINE configs[4] per-GPU size (T=400 x N=256 x M=64 = 6 553 600 samples)."""
+    from mappo_amd import ops
+    tr, b = runner.trainer, runner.buffer
+    cfg = tr._cfg
+    out = {}
+    dev = b.device
+
+    def run(tag, B, logits, values, avail, actions, oldlp, adv, active, vold, ret, vn):
+        mom = torch.zeros(4, dtype=torch.float64, device=dev)
+        ops.minibatch_moments(ret, active, None, B, mom)
+        dl, dv = torch.empty(B, A, device=dev), torch.empty(B, device=dev)
+        st = torch.zeros(6, dtype=torch.float64, device=dev)
+        timer.reset(); timer.active = {"ppo_loss"}
+        if len(timer.pool) < 12:
+            timer.reserve(12)
+        for _ in range(10):
+            ops.ppo_loss_fwd_bwd(logits, values, None, avail, actions, oldlp, adv, active, vold, ret, vn, mom, dl, dv, st, cfg)
+        torch.cuda.synchronize()
+        us = timer.mean_us("ppo_loss")
+        timer.active = set()
+        nbytes = B * 4 * (3 * A + 8)
+        ach = nbytes / (us * 1e-6) / 1e9
+        out[tag] = dict(bound="hbm", kernel="ppo_loss_kernel", samples=B, bytes_per_launch=nbytes, launch_us=us, achieved=ach,
+                        peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+
+    T = b.episode_length
+    S = T * b.n_rollout_threads * b.num_agents
+    adv = tr.compute_advantages(b)
+    run("this_buffer", S, torch.randn(S, A, device=dev), b.value_preds[:T].reshape(S).clone(), b.available_actions[:T].reshape(S, A),
+        b.actions.view(S), b.action_log_probs.view(S), adv, b.active_masks[:T].view(S), b.value_preds[:T].view(S),
+        b.returns[:T].view(S), tr.value_normalizer.state)
+    Bc5 = 400 * 256 * 64
+    g = lambda *s: torch.randn(*s, device=dev)
+    run("configs4_size", Bc5, g(Bc5, A), g(Bc5), torch.ones(Bc5, A, device=dev), torch.randint(0, A, (Bc5,), device=dev).float(),
+        -torch.rand(Bc5, device=dev) - 1.0, g(Bc5), torch.ones(Bc5, device=dev), g(Bc5), g(Bc5), tr.value_normalizer.state)
+    return out
 
 
 def parse():
@@ -76,12 +121,12 @@ class KernelTimer:
             s.record(); e.record()                      # forces creation of the hipEvent handles
             self.pool.append((s, e))
 
-    def arm(self, ops, kernel):
-        if kernel not in self.active or not self.pool:
+    def arm(self, ops, kernel, label):
+        if label not in self.active or not self.pool:
             return
         s, e = self.pool.pop()
         ops.profile_arm(kernel, s, e)
-        self.used.setdefault(kernel, []).append((s, e))
+        self.used.setdefault(label, []).append((s, e))
 
     def mean_us(self, kernel):
         ps = self.used.get(kernel, [])
@@ -94,12 +139,14 @@ class KernelTimer:
 def install_timer(timer):
     """Wrap the ops the trainer calls so that each call arms the hook for its dominant kernel."""
     from mappo_amd import ops
-    for name, kernel in (("ppo_loss_fwd_bwd", "ppo_loss"), ("mlp_backward", "mlp_bwd"), ("mlp_forward", "mlp_fwd"),
-                         ("gae_scan", "gae"), ("clip_adam", "adam"), ("slab_reduce", "slab_reduce"), ("actor_act", "act")):
+    for name, kernel, label in (("ppo_loss_fwd_bwd", "ppo_loss", "ppo_loss"), ("mlp_backward", "mlp_bwd", "mlp_backward"),
+                                ("actor_update", "mlp_bwd", "actor_update"), ("critic_update", "mlp_bwd", "critic_update"),
+                                ("mlp_forward", "mlp_fwd", "mlp_forward"), ("gae_scan", "gae", "gae_scan"),
+                                ("slab_reduce", "slab_reduce", "slab_reduce"), ("actor_act", "act", "actor_act")):
         orig = getattr(ops, name)
 
-        def wrapped(*a, _orig=orig, _k=kernel, **kw):
-            timer.arm(ops, _k)
+        def wrapped(*a, _orig=orig, _k=kernel, _l=label, **kw):
+            timer.arm(ops, _k, _l)
             return _orig(*a, **kw)
         setattr(ops, name, wrapped)
 
@@ -155,11 +202,10 @@ def main():
     runner = MPERunner(dict(all_args=args, envs=env, eval_envs=None, num_agents=M, device=device, run_dir=None, dist_group=dp))
     timer = KernelTimer()
     install_timer(timer)
-    n_loss_launches = ns.steps * args.ppo_epoch * args.num_mini_batch
-    timer.reserve(n_loss_launches + 4 * (args.episode_length + 6 * args.ppo_epoch * args.num_mini_batch + 4))
+    timer.reserve(4 * (args.episode_length + 4 * args.ppo_epoch * args.num_mini_batch + 8) + 64)
 
     runner.warmup()
-    for i in range(ns.warmup):
+    for i in range(max(ns.warmup, 2)):                     # >= 2: eager pass, then hipGraph capture + first replay
         runner.run_episode(i, ns.warmup + ns.steps)
 
     def barrier():
@@ -168,38 +214,47 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    timer.active = {"ppo_loss"}           # timed region: only the roofline kernel carries HIP events
     barrier()
     t0 = time.perf_counter()
     for i in range(ns.steps):
         info, _ = runner.run_episode(ns.warmup + i, ns.warmup + ns.steps)
     barrier()
     dt = time.perf_counter() - t0
-    loss_us = timer.mean_us("ppo_loss")
-    # untimed extra pass: device time of the other hot kernels (informative)
-    timer.reset()
-    timer.active = {"mlp_bwd", "mlp_fwd", "gae", "adam", "slab_reduce", "act"}
-    runner.run_episode(0, 1)
-    torch.cuda.synchronize()
-    kern = {k: timer.mean_us(k) for k in sorted(timer.active) if timer.mean_us(k) is not None}
-    kern["ppo_loss"] = loss_us
-    timer.active = set()
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- per-kernel device time: two more iterations of the SAME step, launched eagerly so that every dispatch of
+    # the hot kernels carries HIP events (hipGraph replays cannot be instrumented from the host) ----
+    graph_flags = (runner._use_graph, runner.trainer._use_graph)
+    runner._use_graph = runner.trainer._use_graph = False
+    labels = ["actor_update", "critic_update", "mlp_forward", "gae_scan", "slab_reduce", "actor_act", "ppo_loss", "mlp_backward"]
+    timer.active = set(labels)
+    for i in range(2):
+        runner.run_episode(0, 1)
+    torch.cuda.synchronize()
+    kern = {k: timer.mean_us(k) for k in labels if timer.mean_us(k) is not None}
+    timer.active = set()
+    runner._use_graph, runner.trainer._use_graph = graph_flags
+
     per_gpu_steps = args.episode_length * args.n_rollout_threads * M
     value = per_gpu_steps * world * ns.steps / dt
-    S = per_gpu_steps // args.num_mini_batch                 # samples per loss-kernel launch
-    bytes_per_sample = 4 * (3 * A + 8)                      # with available_actions (Discrete buffer)
+    S = per_gpu_steps // args.num_mini_batch                 # samples per update-kernel launch
+    H = 64
+    macs_critic = D * M * H + H * H + H                     # forward MACs per sample (share_obs 54 -> 64 -> 64 -> 1)
     roofline = None
-    if loss_us:
-        achieved = S * bytes_per_sample / (loss_us * 1e-6) / 1e9
-        roofline = dict(bound="hbm", kernel="ppo_loss_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=achieved / HBM_PEAK_GBS, traffic=None, bytes_per_launch=S * bytes_per_sample,
-                        launch_us=loss_us)
+    if kern.get("critic_update"):
+        us = kern["critic_update"]
+        flops = S * 6 * macs_critic                          # forward + dW + dX, 2 flop per MAC
+        achieved = flops / (us * 1e-6) / 1e12
+        roofline = dict(bound="mfma", kernel="mlp_update_kernel<relu, layer_N=1, HEAD=critic, wide>", achieved=achieved,
+                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                        flops_per_launch=flops, launch_us=us,
+                        note="algorithmic flops = 6 x forward MACs per sample (forward, dW, dX); the kernel also recomputes the "
+                             "forward (not counted)")
+    loss_roof = ppo_loss_roofline(runner, timer, A)
     out = dict(metric="agent-steps/sec (collect+GAE+PPO), MPE simple_spread 3-agent", value=value, unit="agent-steps/s",
                n_gpus=world, steps=ns.steps, warmup=ns.warmup, ms_per_step=1e3 * dt / ns.steps, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
@@ -209,8 +264,8 @@ def main():
                            n_rollout_threads_per_gpu=args.n_rollout_threads, episode_length=args.episode_length,
                            num_agents=M, ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch,
                            agent_steps_per_step=per_gpu_steps * world, parallelism=f"dp{world}",
-                           exact_minibatch_order=bool(args.exact_minibatch_order)),
-               roofline=roofline, kernels_us=kern,
+                           exact_minibatch_order=bool(args.exact_minibatch_order), hip_graph=bool(graph_flags[1])),
+               roofline=roofline, ppo_loss_roofline=loss_roof, kernels_us=kern,
                last_train_info={k: float(v) for k, v in info.items()})
     if rank == 0:
         if world == 1 and not ns.no_cpu_baseline:

@@ -131,12 +131,34 @@ int mappo_mlp_forward(const float *params, const mappo_net_desc *desc /*host*/, 
                       mappo_stream_t stream);
 int mappo_actor_act(const float *params, const mappo_net_desc *desc /*host*/, const float *obs,
                     const float *avail /*[B][A] or NULL*/, int64_t B, int32_t deterministic,
-                    uint64_t seed, uint64_t counter, float *actions /*[B] fp32 (buffer dtype)*/,
-                    float *logp /*[B]*/, mappo_stream_t stream);
+                    uint64_t seed, uint64_t counter, const uint64_t *counter_dev /*device word added to counter, or NULL*/,
+                    float *actions /*[B] fp32 (buffer dtype)*/, float *logp /*[B]*/, mappo_stream_t stream);
 int32_t mappo_mlp_backward_slabs(int64_t B); /* number of slabs the launch below will write */
 int mappo_mlp_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x,
                        const int32_t *rows, int64_t B, const float *dout /*[B][out_dim]*/,
                        float *slabs, int64_t slab_stride, int64_t slab_col0, mappo_stream_t stream);
+
+/* ---- fused update kernels (K7 + K5 + K7-backward in ONE launch per network; r_mappo.py:91-164) --------------
+ * The forward of a 32-sample tile, the loss gradient at the head and the backward pass run back to back in the
+ * same wavefront: logits / values / d(logits) / d(values) never leave the CU.  Per-sample loss inputs are read
+ * in buffer order through `rows` (NULL = identity), exactly like mappo_ppo_loss_fwd_bwd, whose arithmetic they
+ * share.  Outputs: one gradient slab per workgroup (as mappo_mlp_backward) and per-workgroup double partial
+ * sums `partials[n_slabs][4]` (actor: sum w*min(s1,s2), sum w*H, sum ratio, - ; critic: sum w_v*l, -, -, -),
+ * turned into the 6 statistics by mappo_update_stats (actor_partials may be NULL when update_actor is off). */
+int64_t mappo_update_partials_bytes(void);
+int mappo_actor_update(const float *params, const mappo_net_desc *desc /*host*/, const float *obs,
+                       const int32_t *rows, int64_t B, const float *avail /*or NULL*/, const float *actions,
+                       const float *old_logp, const float *adv, const float *active,
+                       const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
+                       int64_t slab_stride, int64_t slab_col0, double *partials, mappo_stream_t stream);
+int mappo_critic_update(const float *params, const mappo_net_desc *desc /*host*/, const float *share_obs,
+                        const int32_t *rows, int64_t B, const float *v_old, const float *returns,
+                        const float *active, const float *vn_state /*[3] after update, or NULL*/,
+                        const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
+                        int64_t slab_stride, int64_t slab_col0, double *partials, mappo_stream_t stream);
+int mappo_update_stats(const double *actor_partials, const double *critic_partials, int64_t B,
+                       const double *mb_moments, const mappo_ppo_cfg *cfg /*host*/, double *stats /*[6]*/,
+                       mappo_stream_t stream);
 
 /* ---- K10/K11: slab reduction, global-norm clip, Adam (r_mappo.py:143-148,157-162; torch Adam) -------
  * The flat gradient covers `n_seg` parameter segments (actor, critic); norms/clip/lr are per segment.
@@ -151,8 +173,8 @@ int mappo_clip_adam(float *params, const float *grad, float *exp_avg, float *exp
                     const float *opt_hyper, int32_t *opt_step, float *grad_norms, void *workspace,
                     mappo_stream_t stream);
 
-/* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel is bracketed by the two
- * hipEvent_t handles, recorded on the stream that launch uses; the hook disarms itself after one use. */
+/* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel carries the two hipEvent_t
+ * handles (hipExtLaunchKernelGGL: start / stop of that dispatch on its own stream); the hook disarms after one use. */
 #define MAPPO_PROF_GAE 0
 #define MAPPO_PROF_PPO_LOSS 1
 #define MAPPO_PROF_MLP_FWD 2

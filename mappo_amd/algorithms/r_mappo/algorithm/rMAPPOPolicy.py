@@ -139,7 +139,7 @@ class R_MAPPOPolicy:
         out = (buffer.actions[step].view(R), buffer.action_log_probs[step].view(R))
         masks = buffer.masks[step].view(R, 1)
         _, _, rnn_a = self.actor(buffer.obs[step].view(R, -1), buffer.rnn_states[step].view(R, buffer.recurrent_N, -1),
-                                 masks, avail, deterministic, out=out)
+                                 masks, avail, deterministic, out=out, counter=step)
         _, rnn_c = self.critic(buffer.share_obs[step].view(R, -1),
                                buffer.rnn_states_critic[step].view(R, buffer.recurrent_N, -1), masks,
                                out=buffer.value_preds[step].view(R, 1))

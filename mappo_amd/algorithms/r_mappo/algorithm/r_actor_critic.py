@@ -93,10 +93,15 @@ class R_Actor(_NetBase):
                                                   args.gain, self._recurrent))
         self._sample_counter = 0
         self._seed = int(getattr(args, "seed", 1))
+        # device word added to the sampling counter inside the kernel: a captured hipGraph bakes the host counter,
+        # so the rollout graph bumps this word once per replay to keep drawing fresh random numbers
+        self._counter_dev = torch.zeros(1, dtype=torch.int64, device=self.device_)
 
     # r_actor_critic.py:43-70
     @torch.no_grad()
-    def forward(self, obs, rnn_states, masks, available_actions=None, deterministic=False, out=None):
+    def forward(self, obs, rnn_states, masks, available_actions=None, deterministic=False, out=None, counter=None):
+        """`out=(actions_f32[B], logp[B])` writes in place (fused rollout); `counter` fixes the host part of the
+        sampling counter (the runner passes the step index so that eager and graph-replayed rollouts agree)."""
         obs = self._in(obs)
         B = obs.shape[0]
         avail = self._in(available_actions) if available_actions is not None else None
@@ -109,9 +114,12 @@ class R_Actor(_NetBase):
             from mappo_amd.recurrent import actor_step
             rnn_states = actor_step(self, obs, self._in(rnn_states), self._in(masks), avail, deterministic, actions_f, logp)
         else:
-            ops.actor_act(self.flat, self.desc, obs, avail, B, deterministic, self._seed, self._sample_counter, actions_f, logp)
+            if counter is None:
+                counter = self._sample_counter
+                self._sample_counter += 1
+            ops.actor_act(self.flat, self.desc, obs, avail, B, deterministic, self._seed, counter, actions_f, logp,
+                          self._counter_dev)
             rnn_states = rnn_states if torch.is_tensor(rnn_states) else self._in(rnn_states)
-        self._sample_counter += 1
         if out is not None:
             return actions_f, logp, rnn_states
         return actions_f.long().view(B, 1), logp.view(B, 1), rnn_states

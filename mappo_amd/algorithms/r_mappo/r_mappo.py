@@ -3,8 +3,13 @@
 `train(buffer)` keeps the reference's structure (advantage normalisation, ppo_epoch x num_mini_batch updates,
 six averaged statistics) but every update is a fixed sequence of HIP launches on the HBM-resident buffer:
 
-    minibatch moments -> ValueNorm update -> actor/critic forward (MFMA) -> fused PPO loss fwd+bwd ->
-    actor/critic backward (MFMA, forward recomputed) -> slab reduce -> [RCCL all-reduce] -> clip + Adam
+    minibatch moments -> ValueNorm update -> actor update kernel -> critic update kernel ->
+    slab reduce -> [RCCL all-reduce] -> clip + Adam
+
+where an "update kernel" (mappo_actor_update / mappo_critic_update) runs forward, PPO loss gradient and backward
+of one network per 32-sample tile inside one wavefront, so logits / values / their gradients never reach HBM.
+`--unfused_update` switches to the equivalent five-launch sequence (forward x2, mappo_ppo_loss_fwd_bwd,
+backward x2) built from the standalone ops.
 
 The minibatch is never materialised: kernels take int32 row indices into the buffer (or stream it in place
 when num_mini_batch == 1, where the permutation only reorders the terms of sums).  No `.item()` inside the
@@ -44,6 +49,9 @@ class R_MAPPO():
         self._use_value_active_masks = args.use_value_active_masks
         self._use_policy_active_masks = args.use_policy_active_masks
         self._exact_order = bool(getattr(args, "exact_minibatch_order", False))
+        self._fused = not bool(getattr(args, "unfused_update", False))
+        self._use_graph = bool(getattr(args, "use_hip_graph", True))
+        self._graphs = {}
 
         assert (self._use_popart and self._use_valuenorm) == False, \
             "self._use_popart and self._use_valuenorm can not be set True simultaneously"
@@ -86,27 +94,35 @@ class R_MAPPO():
             self._dist.all_reduce_sum_(self._mb_moments)
         if self._use_valuenorm:
             ops.valuenorm_update(vn_state, self._mb_moments, self.value_normalizer.beta)
-        # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
-        logits = self._buf("logits", (B, A))
-        values = self._buf("values", (B,))
-        ops.mlp_forward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, logits)
-        ops.mlp_forward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, values)
-        # fused loss forward + backward
-        dlogits = self._buf("dlogits", (B, A))
-        dvalues = self._buf("dvalues", (B,))
-        ops.ppo_loss_fwd_bwd(logits, values, rows, src["avail"], src["actions"], src["old_logp"], src["adv"], src["active"],
-                             src["v_old"], src["returns"], vn_state, self._mb_moments, dlogits, dvalues, self._stats,
-                             self._cfg, self._bytes("loss_ws", lib.mappo_ppo_loss_workspace_bytes(B)))
-        # backward through both networks into per-workgroup slabs over the joint flat layout
         n_slabs = ops.mlp_backward_slabs(B)
         P = pol.n_flat
         slabs = self._buf("slabs", (n_slabs, P), zero=True)
-        if update_actor:
-            ops.mlp_backward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, dlogits, slabs, P, 0)
-        elif not self._actor_slabs_clean:
+        if not update_actor and not self._actor_slabs_clean:
             slabs[:, :pol.seg_bounds[1]].zero_()
         self._actor_slabs_clean = not update_actor
-        ops.mlp_backward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, dvalues, slabs, P, pol.seg_bounds[1])
+        if self._fused:
+            pa = self._buf("partials_a", (1024,), torch.float64, zero=True)
+            pc = self._buf("partials_c", (1024,), torch.float64, zero=True)
+            if update_actor:
+                ops.actor_update(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, src["avail"], src["actions"],
+                                 src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa)
+            ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
+                              src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc)
+            ops.update_stats(pa if update_actor else None, pc, B, self._mb_moments, self._cfg, self._stats)
+        else:
+            # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
+            logits = self._buf("logits", (B, A))
+            values = self._buf("values", (B,))
+            ops.mlp_forward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, logits)
+            ops.mlp_forward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, values)
+            dlogits = self._buf("dlogits", (B, A))
+            dvalues = self._buf("dvalues", (B,))
+            ops.ppo_loss_fwd_bwd(logits, values, rows, src["avail"], src["actions"], src["old_logp"], src["adv"],
+                                 src["active"], src["v_old"], src["returns"], vn_state, self._mb_moments, dlogits, dvalues,
+                                 self._stats, self._cfg, self._bytes("loss_ws", lib.mappo_ppo_loss_workspace_bytes(B)))
+            if update_actor:
+                ops.mlp_backward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, dlogits, slabs, P, 0)
+            ops.mlp_backward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, dvalues, slabs, P, pol.seg_bounds[1])
         ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
         if self._dist is not None:
             self._dist.all_reduce_sum_(pol.flat_grad)          # C1: one flat fp32 all-reduce per minibatch
@@ -134,10 +150,37 @@ class R_MAPPO():
 
     # ---- r_mappo.py:166-219 ---------------------------------------------------------------------------------
     @torch.no_grad()
-    def train(self, buffer, update_actor=True):
+    def train(self, buffer, update_actor=True, after_update=False):
+        """`after_update=True` also performs buffer.after_update() (base_runner.py:124) inside the same launch
+        sequence.  With num_mini_batch == 1 the whole sequence (advantages, ppo_epoch updates, after_update) is
+        captured into ONE hipGraph after a first eager run and replayed afterwards: the inner loop is a fixed
+        chain of ~15 short kernels per update, launch-bound when issued from Python."""
         if self._use_recurrent_policy or self._use_naive_recurrent:
             from mappo_amd.recurrent import train_recurrent
-            return train_recurrent(self, buffer, update_actor)
+            info = train_recurrent(self, buffer, update_actor)
+            if after_update:
+                buffer.after_update()
+            return info
+        static = self.num_mini_batch == 1 and not self._exact_order       # no randperm inside => capturable
+        if not (self._use_graph and static and self._dist is None):
+            self._train_body(buffer, update_actor, after_update)
+            return self._finish_train_info()
+        key = (id(buffer), bool(update_actor), bool(after_update))
+        state = self._graphs.get(key)
+        if state is None:
+            self._train_body(buffer, update_actor, after_update)           # eager: allocates workspaces, sets attributes
+            self._graphs[key] = "warm"
+        else:
+            if state == "warm":
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._train_body(buffer, update_actor, after_update)
+                self._graphs[key] = state = g
+            state.replay()
+        return self._finish_train_info()
+
+    def _train_body(self, buffer, update_actor, after_update):
         T = buffer.episode_length
         S = T * buffer.n_rollout_threads * buffer.num_agents
         adv = self.compute_advantages(buffer)
@@ -150,7 +193,8 @@ class R_MAPPO():
                 batches = [(rows, rows.numel()) for rows in buffer.feed_forward_rows(self.num_mini_batch)]
             for rows, B in batches:
                 self._update(src, rows, B, update_actor)
-        return self._finish_train_info()
+        if after_update:
+            buffer.after_update()
 
     def compute_advantages(self, buffer):
         """r_mappo.py:174-182 as two kernels around an (optional) 3-double all-reduce."""

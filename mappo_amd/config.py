@@ -83,6 +83,12 @@ def get_config():
                    help="with num_mini_batch == 1 the minibatch is the whole buffer and its permutation only reorders "
                         "the terms of sums; by default the kernels then stream the buffer in place. Set to gather by "
                         "the random permutation anyway (what the reference's generator does).")
+    p.add_argument("--unfused_update", **on,
+                   help="run each PPO update as separate forward / fused-loss / backward launches (the standalone C-ABI ops) "
+                        "instead of the one-launch-per-network update kernels; same results")
+    p.add_argument("--use_hip_graph", **off,
+                   help="by default the launch-bound inner loops (PPO updates; rollout with a graph-safe env) are captured "
+                        "into hipGraphs after one eager pass; pass the flag to always launch eagerly")
     p.add_argument("--perm_device", type=str, default="cuda", choices=["cuda", "cpu"],
                    help="where torch.randperm runs; 'cpu' reproduces the reference's permutation stream bit-exactly")
     return p

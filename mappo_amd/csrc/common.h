@@ -1,6 +1,7 @@
 // common.h — shared helpers for the gfx950 kernels of libmappo_hip.so (wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -19,6 +20,8 @@ void mappo_set_error(const char *fmt, ...);
     }                                       \
   } while (0)
 
+#define MAPPO_CLEAR_STICKY() (void)hipGetLastError()
+
 #define MAPPO_CHECK_LAUNCH(name)                                              \
   do {                                                                        \
     hipError_t e_ = hipGetLastError();                                        \
@@ -33,6 +36,17 @@ static inline hipStream_t as_stream(mappo_stream_t s) { return (hipStream_t)s; }
 // ---- one-shot HIP-event bracket around the dominant kernel of an entry point (mappo_profile_arm) ----------
 struct ProfSlot { hipEvent_t start, stop; };
 extern ProfSlot g_prof[MAPPO_PROF_COUNT];
+// Launch `kernel`; when the hook `id` is armed, its two events are attached to THIS dispatch (start = kernel
+// begin, stop = kernel end: the same timestamps rocprofv3's kernel trace reports) and the hook disarms.
+#define PROF_LAUNCH(id, kernel, grid, block, lds, st, ...)                                                   \
+  do {                                                                                                        \
+    if (g_prof[id].start && g_prof[id].stop) {                                                                \
+      hipExtLaunchKernelGGL(kernel, grid, block, lds, st, g_prof[id].start, g_prof[id].stop, 0, __VA_ARGS__); \
+      g_prof[id].start = g_prof[id].stop = nullptr;                                                           \
+    } else {                                                                                                  \
+      hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__);                                          \
+    }                                                                                                         \
+  } while (0)
 #define PROF_BEGIN(id, st) do { if (g_prof[id].start) (void)hipEventRecord(g_prof[id].start, st); } while (0)
 #define PROF_END(id, st)                                                     \
   do {                                                                       \

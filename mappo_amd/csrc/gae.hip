@@ -104,12 +104,10 @@ extern "C" int mappo_gae_scan(const float *rewards, float *value_preds, const fl
   dim3 grid((R + WAVE - 1) / WAVE), block(WAVE * S);
   hipStream_t st = as_stream(stream);
 #define LAUNCH(G, P)                                                                                          \
-  hipLaunchKernelGGL((gae_scan_kernel<G, P>), grid, block, 0, st, rewards, value_preds, next_value, masks, \
-                     bad_masks, returns, vn_state, (int)T, (int)R, gamma, gamlam, Lseg)
-  PROF_BEGIN(MAPPO_PROF_GAE, st);
+  PROF_LAUNCH(MAPPO_PROF_GAE, (gae_scan_kernel<G, P>), grid, block, 0, st, rewards, value_preds, next_value, masks, \
+              bad_masks, returns, vn_state, (int)T, (int)R, gamma, gamlam, Lseg)
   if (use_gae) { if (use_proper_time_limits) LAUNCH(true, true); else LAUNCH(true, false); }
   else         { if (use_proper_time_limits) LAUNCH(false, true); else LAUNCH(false, false); }
-  PROF_END(MAPPO_PROF_GAE, st);
 #undef LAUNCH
   MAPPO_CHECK_LAUNCH("gae_scan");
   return MAPPO_OK;

@@ -1,5 +1,5 @@
-// mlp.hip — K7 / K6 / K8: the shared actor/critic MLP (onpolicy/algorithms/utils/mlp.py:6-55) with its
-// head (distributions.py:55-68 logits, r_actor_critic.py:136-165 v_out) on the fp32 matrix cores.
+// mlp.hip — K7 / K6 / K8 (+K5 fused): the shared actor/critic MLP (onpolicy/algorithms/utils/mlp.py:6-55) with
+// its head (distributions.py:55-68 logits, r_actor_critic.py:136-165 v_out) on the fp32 matrix cores.
 //
 //   trunk:  x -> LN_D -> Linear(D,64) -> act -> LN_64 -> [Linear(64,64) -> act -> LN_64] x layer_N -> head
 //
@@ -14,16 +14,25 @@
 // read transposed (lanes <-> feature, k <-> sample), as both operands of the weight-gradient products.
 // A tile stores the NORMALISED value xhat = (a - mean) * rstd of its LayerNorm; the affine (gamma, beta) is
 // applied when the tile is read as an operand (two broadcast LDS reads + one FMA per MFMA pair), so the
-// backward pass finds xhat in the tile and only mean/rstd (2 registers) survive from the forward.
+// backward pass finds xhat in the tile and only mean/rstd/sign-mask (3 registers) survive from the forward.
 //
-// mappo_mlp_backward recomputes the forward per tile instead of reading saved activations back from HBM
-// (saving 64*4*(2+layer_N) B/sample each way at the cost of ~1/3 more MFMA work), keeps dW accumulators in
-// registers across its persistent tile loop, and writes ONE partial-gradient slab per workgroup; the slabs
-// are summed by mappo_slab_reduce (deterministic, no float atomics).
+// Kernels
+//   mlp_forward_kernel  MODE 0: out = head(trunk(x[rows]))           (evaluate_actions / get_values)
+//                       MODE 1: + availability mask, sample|argmax, log-prob  (get_actions / act)
+//   mlp_update_kernel   forward, head gradient, backward and weight-gradient accumulation in ONE launch:
+//                       HEAD 0: head gradient supplied by the caller (mappo_mlp_backward)
+//                       HEAD 1: actor  — PPO clipped surrogate + entropy computed in the kernel from the logits
+//                       HEAD 2: critic — clipped Huber|MSE value loss computed in the kernel from the values
+//                       (r_mappo.py:52-89,124-141: logits / values / their gradients never touch HBM).
+//   The forward is recomputed per tile instead of reading saved activations back from HBM, dW accumulators
+//   stay in registers across the persistent tile loop, the next tile's rows are prefetched into registers
+//   under the current tile's MFMA chains, and every workgroup writes ONE partial-gradient slab, summed by
+//   mappo_slab_reduce (deterministic, no float atomics).
 //
 // Limits of this build: hidden == 64, out_dim <= 32, layer_N <= 2, in_dim <= 64 (the K-chunked layer-1 path
 // for wider observations is a separate kernel).
 #include "common.h"
+#include <float.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -69,22 +78,24 @@ extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS carve-up (floats).  Dp = in_dim rounded up to even.
+// LDS carve-up (floats); every region starts on a 16-byte boundary.  Dp = in_dim rounded up to even.
+// Per wave: tX [Dp rows] | tH [(layer_N+1) x 64 rows] | tZ [32 rows: head output / head gradient as [s][a]].
 // ------------------------------------------------------------------------------------------------
 struct LdsMap {
-  int w1, w2[MAPPO_MAX_LAYER_N], wh;          // weights
+  int w1, w2[MAPPO_MAX_LAYER_N], wh;
   int fn_w, fn_b, b1, ln1_w, ln1_b, b2[MAPPO_MAX_LAYER_N], ln2_w[MAPPO_MAX_LAYER_N], ln2_b[MAPPO_MAX_LAYER_N], bh;
-  int tiles;                                   // start of the per-wave tile area
-  int tiles_per_wave, wave_stride, total;
+  int tiles, x_rows, wave_stride, total;
 };
 
-__host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves, int tiles_per_wave) {
+__host__ __device__ inline int al4(int p) { return (p + 3) & ~3; }
+
+__host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves) {
   LdsMap m;
   int p = 0;
   const int Dp = (d.in_dim + 1) & ~1;
-  m.w1 = p; p += Dp * WP;
-  for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) { m.w2[l] = p; if (l < d.layer_N) p += HID * WP; }
-  m.wh = p; p += HID * HP;
+  m.w1 = p; p = al4(p + Dp * WP);
+  for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) { m.w2[l] = p; if (l < d.layer_N) p = al4(p + HID * WP); }
+  m.wh = p; p = al4(p + HID * HP);
   m.fn_w = p; p += MAXD; m.fn_b = p; p += MAXD;
   m.b1 = p; p += HID; m.ln1_w = p; p += HID; m.ln1_b = p; p += HID;
   for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) {
@@ -92,10 +103,9 @@ __host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves, 
     if (l < d.layer_N) { m.b2[l] = p; p += HID; m.ln2_w[l] = p; p += HID; m.ln2_b[l] = p; p += HID; }
   }
   m.bh = p; p += 32;
-  p = (p + 3) & ~3;
   m.tiles = p;
-  m.tiles_per_wave = tiles_per_wave;
-  m.wave_stride = tiles_per_wave * HID * TP;
+  m.x_rows = Dp;
+  m.wave_stride = al4((Dp + (d.layer_N + 1) * HID + TS) * TP);
   p += n_waves * m.wave_stride;
   m.total = p;
   return m;
@@ -119,20 +129,52 @@ __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 3
 
 template <bool RELU>
 __device__ __forceinline__ float act_fwd(float z) { return RELU ? fmaxf(z, 0.f) : tanhf(z); }
-template <bool RELU>
-__device__ __forceinline__ float act_bwd(float a, float da) { return RELU ? (a > 0.f ? da : 0.f) : da * (1.f - a * a); }
 
 __device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// Workgroup-cooperative staging of the weights: global W[f][k] (row-major, K columns) -> LDS dst[k*stride + f].
+// 4 consecutive features (reg&3 = 0..3) of a per-feature vector in LDS, as one 16-byte read
+__device__ __forceinline__ float4 vec4_of(const float *sV, int t, int q, int half) {
+  return *reinterpret_cast<const float4 *>(sV + 32 * t + 8 * q + 4 * half);
+}
+
+// Workgroup-cooperative staging: global W[f][k] (row-major, K columns) -> LDS dst[k*stride + f], rows k in
+// [K, Kpad) zeroed.  All global loads of a thread are issued before its LDS writes (16-byte loads when aligned).
 __device__ __forceinline__ void stage_weight_T(float *dst, const float *__restrict__ src, int F, int K, int Kpad, int stride) {
-  for (int e = threadIdx.x; e < F * K; e += blockDim.x) {
-    const int f = e / K, k = e - f * K;
-    dst[k * stride + f] = src[e];
+  const int total = F * K;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  if ((((uintptr_t)src) & 15) == 0 && (total & 3) == 0) {
+    const int n4 = total >> 2;
+    for (int i0 = 0; i0 < n4; i0 += 8 * nthr) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * nthr + tid;
+        if (i < n4) v[j] = reinterpret_cast<const float4 *>(src)[i];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int i = i0 + j * nthr + tid;
+        if (i < n4) {
+          const int e = i << 2;
+          int f = e / K, k = e - f * K;
+          const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            dst[k * stride + f] = vv[c];
+            if (++k == K) { k = 0; ++f; }
+          }
+        }
+      }
+    }
+  } else {
+    for (int e = tid; e < total; e += nthr) {
+      const int f = e / K, k = e - f * K;
+      dst[k * stride + f] = src[e];
+    }
   }
-  for (int e = threadIdx.x; e < F * (Kpad - K); e += blockDim.x) {   // zero the padded k rows
+  for (int e = tid; e < F * (Kpad - K); e += nthr) {
     const int f = e % F, k = K + e / F;
     dst[k * stride + f] = 0.f;
   }
@@ -150,7 +192,7 @@ __device__ __forceinline__ void stage_all_weights(float *lds, const LdsMap &m, c
   for (int l = 0; l < LN; ++l) stage_weight_T(lds + m.w2[l], params + o.w2[l], HID, HID, HID, WP);
   // head: dst[k*HP + a] = Wh[a][k]; columns a >= A are zero
   for (int e = threadIdx.x; e < HID * 32; e += blockDim.x) {
-    const int k = e >> 5, a = e & 31;
+    const int a = e >> 6, k = e & 63;                       // consecutive threads read consecutive k of row a
     lds[m.wh + k * HP + a] = (a < A) ? params[o.wh + a * HID + k] : 0.f;
   }
   if (d.use_feature_norm) {
@@ -171,27 +213,46 @@ __device__ __forceinline__ void stage_all_weights(float *lds, const LdsMap &m, c
   stage_vec(lds + m.bh, params + o.bh, A, 32, 0.f);
 }
 
-// Gather a tile of 32 input rows into tX[k][s] (raw values), zero for samples >= n_valid and for k in [D, Dp).
-__device__ __forceinline__ void gather_tile(float *tX, const float *__restrict__ x, const int32_t *__restrict__ rows,
-                                            int64_t base, int n_valid, int D, int Dp, int lane) {
-  // lane s (< 32) learns the source row of sample s; rows are then broadcast with shuffles
-  int64_t my_row = 0;
-  if (lane < TS && lane < n_valid) my_row = rows ? (int64_t)rows[base + lane] : base + lane;
-  const int per = (D <= 32) ? 2 : 1;            // samples fetched per wave-instruction
-  const int kl = (per == 2) ? (lane & 31) : lane;
-  const int sub = (per == 2) ? (lane >> 5) : 0;
-#pragma unroll 8
-  for (int s0 = 0; s0 < TS; s0 += per) {
-    const int s = s0 + sub;
-    const int64_t row = __shfl(my_row, s, WAVE);
-    float v = 0.f;
-    if (kl < D && s < n_valid) v = x[row * D + kl];
-    if (kl < Dp) tX[kl * TP + s] = v;
+// ------------------------------------------------------------------------------------------------
+// input rows: register prefetch (global -> VGPR for the NEXT tile) and LDS commit (VGPR -> tX[k][s])
+// ------------------------------------------------------------------------------------------------
+// WIDE = false (in_dim <= 32): a wave-instruction fetches two samples (lanes 0-31 / 32-63), 16 registers;
+// WIDE = true  (in_dim <= 64): one sample per wave-instruction, 32 registers.
+template <bool WIDE>
+struct RowPrefetch {
+  float v[WIDE ? TS : TS / 2];
+  int my_row;         // lane s < 32: source row of sample s of the prefetched tile
+  int n_valid;
+};
+
+template <bool WIDE>
+__device__ __forceinline__ void prefetch_rows(RowPrefetch<WIDE> &pf, const float *__restrict__ x,
+                                              const int32_t *__restrict__ rows, int64_t base, int64_t B, int D, int lane) {
+  pf.n_valid = (int)max((int64_t)0, min((int64_t)TS, B - base));
+  pf.my_row = 0;
+  if (lane < pf.n_valid) pf.my_row = rows ? rows[base + lane] : (int)(base + lane);
+  const int kl = WIDE ? lane : (lane & 31), sub = WIDE ? 0 : (lane >> 5);
+  constexpr int NV = WIDE ? TS : TS / 2, STEP = WIDE ? 1 : 2;
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int s = j * STEP + sub;
+    const int row = __shfl(pf.my_row, s, WAVE);
+    pf.v[j] = 0.f;
+    if (kl < D && s < pf.n_valid) pf.v[j] = x[(int64_t)row * D + kl];
   }
 }
 
+template <bool WIDE>
+__device__ __forceinline__ void commit_rows(float *tX, const RowPrefetch<WIDE> &pf, int Dp, int lane) {
+  const int kl = WIDE ? lane : (lane & 31), sub = WIDE ? 0 : (lane >> 5);
+  constexpr int NV = WIDE ? TS : TS / 2, STEP = WIDE ? 1 : 2;
+#pragma unroll
+  for (int j = 0; j < NV; ++j)
+    if (kl < Dp) tX[kl * TP + j * STEP + sub] = pf.v[j];
+}
+
 // LayerNorm over the D input features of each sample, in place: tX <- xhat0 (the affine is applied on read).
-__device__ __forceinline__ void feature_norm_tile(float *tX, int D, int Dp, int l31, int half, bool enabled) {
+__device__ __forceinline__ void feature_norm_tile(float *tX, int D, int l31, int half, bool enabled) {
   if (!enabled) return;
   float s = 0.f;
   for (int k = half; k < D; k += 2) s += tX[k * TP + l31];
@@ -207,7 +268,10 @@ __device__ __forceinline__ void init_bias(f32x16 (&acc)[2], const float *sB, int
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = sB[32 * t + ROWMAP(r, half)];
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = vec4_of(sB, t, q, half);
+      acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
+    }
 }
 
 // act + LayerNorm(64) statistics in the accumulator layout.  On return acc holds a = act(z).
@@ -235,24 +299,28 @@ __device__ __forceinline__ void xhat_to_tile(float *tile, const f32x16 (&a)[2], 
     for (int r = 0; r < 16; ++r) tile[(32 * t + ROWMAP(r, half)) * TP + l31] = (a[t][r] - mean) * rstd;
 }
 
-// acc[t] += W-tile . (tin * gamma + beta)   (forward layer; weights k-major in LDS, K = 2*ksteps)
+// acc[t] += W-tile . (tin * gamma + beta)   (forward layer; weights k-major in LDS, K = 2*ksteps); operands of
+// step kk+1 are fetched from LDS before the MFMAs of step kk issue
 __device__ __forceinline__ void layer_mfma(f32x16 (&acc)[2], const float *sW, const float *tin, const float *sG,
                                            const float *sBt, int ksteps, int l31, int half) {
+  int k = half;
+  float b = tin[k * TP + l31] * sG[k] + sBt[k];
+  float a0 = sW[k * WP + l31], a1 = sW[k * WP + 32 + l31];
 #pragma unroll 2
   for (int kk = 0; kk < ksteps; ++kk) {
-    const int k = 2 * kk + half;
-    const float b = tin[k * TP + l31] * sG[k] + sBt[k];
-    const float a0 = sW[k * WP + l31];
-    const float a1 = sW[k * WP + 32 + l31];
+    float nb = 0.f, na0 = 0.f, na1 = 0.f;
+    if (kk + 1 < ksteps) {
+      k += 2;
+      nb = tin[k * TP + l31] * sG[k] + sBt[k];
+      na0 = sW[k * WP + l31];
+      na1 = sW[k * WP + 32 + l31];
+    }
     acc[0] = mfma(a0, b, acc[0]);
     acc[1] = mfma(a1, b, acc[1]);
+    b = nb; a0 = na0; a1 = na1;
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// forward of one 32-sample tile.  SAVE keeps the post-activation values and LN statistics for backward.
-// Tiles: tX (xhat0), tH[0..layer_N] (layer outputs h_1 .. h_{layer_N+1}).
-// ------------------------------------------------------------------------------------------------
 template <int LN>
 struct TileStats {
   float mean[LN + 1], rstd[LN + 1];
@@ -274,19 +342,18 @@ __device__ __forceinline__ int ln_w_of(const LdsMap &m, int l) { return l == 0 ?
 template <int LN>
 __device__ __forceinline__ int ln_b_of(const LdsMap &m, int l) { return l == 0 ? m.ln1_b : m.ln2_b[l - 1]; }
 
+// forward of one 32-sample tile: tX (xhat0) -> tH[0..LN] (xhat of every LayerNorm); statistics kept for backward
 template <bool RELU, int LN>
 __device__ __forceinline__ void tile_forward(const float *lds, const LdsMap &m, float *tX, float *tH, int D, int l31, int half,
                                              TileStats<LN> &st) {
   const int Dp = (D + 1) & ~1;
   f32x16 acc[2];
-  // ---- layer 1 (input = xhat0 with the feature-norm affine applied on read) ----
   init_bias(acc, lds + m.b1, half);
   layer_mfma(acc, lds + m.w1, tX, lds + m.fn_w, lds + m.fn_b, Dp / 2, l31, half);
   act_ln_stats<RELU>(acc, st.mean[0], st.rstd[0]);
   st.pos[0] = positive_mask(acc);
   xhat_to_tile(tH, acc, st.mean[0], st.rstd[0], l31, half);
   wave_lds_sync();
-  // ---- hidden layers ----
 #pragma unroll
   for (int l = 0; l < LN; ++l) {
     init_bias(acc, lds + m.b2[l], half);
@@ -303,14 +370,34 @@ __device__ __forceinline__ f32x16 head_forward(const float *lds, const LdsMap &m
                                                const float *sBt, int l31, int half) {
   f32x16 acc;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = lds[m.bh + ROWMAP(r, half)];
+  for (int q = 0; q < 4; ++q) {
+    const float4 b = *reinterpret_cast<const float4 *>(lds + m.bh + 8 * q + 4 * half);
+    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+  }
   const float *sW = lds + m.wh;
-#pragma unroll 4
+  int k = half;
+  float a = sW[k * HP + l31], b = tLast[k * TP + l31] * sG[k] + sBt[k];
+#pragma unroll 2
   for (int kk = 0; kk < HID / 2; ++kk) {
-    const int k = 2 * kk + half;
-    acc = mfma(sW[k * HP + l31], tLast[k * TP + l31] * sG[k] + sBt[k], acc);
+    float na = 0.f, nb = 0.f;
+    if (kk + 1 < HID / 2) {
+      k += 2;
+      na = sW[k * HP + l31];
+      nb = tLast[k * TP + l31] * sG[k] + sBt[k];
+    }
+    acc = mfma(a, b, acc);
+    a = na; b = nb;
   }
   return acc;
+}
+
+// head output (accumulator layout) -> tZ[s][a]
+__device__ __forceinline__ void head_to_tile(float *tZ, const f32x16 &z, int A, int l31, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int a = ROWMAP(r, half);
+    if (a < A) tZ[l31 * TP + a] = z[r];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -343,50 +430,51 @@ struct FwdArgs {
   int64_t B;
   int deterministic;
   uint64_t seed, counter;
+  const uint64_t *counter_dev;   // optional device word added to `counter` (lets a captured hipGraph draw fresh numbers)
 };
 
-template <bool RELU, int LN, int MODE>
+template <bool RELU, int LN, int MODE, bool WIDE>
 __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
   extern __shared__ __align__(16) float lds[];
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
-  stage_all_weights<LN>(lds, m, p.params, o, p.desc);
-  __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
   const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
-  float *tX = lds + m.tiles + wave * m.wave_stride;
-  float *tH = tX + HID * TP;
   const int64_t n_tiles = (p.B + TS - 1) / TS;
-  for (int64_t tile = (int64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * n_waves) {
+  const int64_t tile_stride = (int64_t)gridDim.x * n_waves;
+  int64_t tile = (int64_t)blockIdx.x * n_waves + wave;
+  RowPrefetch<WIDE> pf;
+  prefetch_rows(pf, p.x, p.rows, tile * TS, p.B, D, lane);       // in flight while the weights are staged
+  stage_all_weights<LN>(lds, m, p.params, o, p.desc);
+  __syncthreads();
+  float *tX = lds + m.tiles + wave * m.wave_stride;
+  float *tH = tX + m.x_rows * TP;
+  float *tZ = tH + (LN + 1) * HID * TP;
+  for (; tile < n_tiles; tile += tile_stride) {
     const int64_t base = tile * TS;
-    const int n_valid = (int)min((int64_t)TS, p.B - base);
-    gather_tile(tX, p.x, p.rows, base, n_valid, D, Dp, lane);
+    const int n_valid = pf.n_valid;
+    commit_rows(tX, pf, Dp, lane);
     wave_lds_sync();
-    feature_norm_tile(tX, D, Dp, l31, half, p.desc.use_feature_norm != 0);
+    prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);
+    feature_norm_tile(tX, D, l31, half, p.desc.use_feature_norm != 0);
     wave_lds_sync();
     TileStats<LN> st;
     tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
     const f32x16 z = head_forward(lds, m, tH + LN * HID * TP, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN), l31, half);
-    // stage the head output as [s][a] (row stride TP) in tX, which is free now
-    wave_lds_sync();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int a = ROWMAP(r, half);
-      if (a < A) tX[l31 * TP + a] = z[r];
-    }
+    head_to_tile(tZ, z, A, l31, half);
     wave_lds_sync();
     if (MODE == 0) {
       for (int e = lane; e < n_valid * A; e += WAVE) {
         const int s = e / A, a = e - s * A;
-        p.out[base * A + e] = tX[s * TP + a];
+        p.out[base * A + e] = tZ[s * TP + a];
       }
     } else {
       if (lane < n_valid) {
-        float *zl = tX + lane * TP;
+        float *zl = tZ + lane * TP;
         const int64_t i = base + lane;
         const float *av = p.avail ? p.avail + i * A : nullptr;
-        float zmax = -3.4e38f;
+        float zmax = -FLT_MAX;
         for (int a = 0; a < A; ++a) {
           float za = zl[a];
           if (av && av[a] == 0.f) { za = -1e10f; zl[a] = za; }
@@ -397,10 +485,11 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
         const float lse = zmax + logf(se);
         int chosen = 0;
         if (p.deterministic) {
-          float best = -3.4e38f;                       // probs.argmax: first maximum
+          float best = -FLT_MAX;                         // probs.argmax: first maximum
           for (int a = 0; a < A; ++a) { if (zl[a] > best) { best = zl[a]; chosen = a; } }
         } else {
-          const float u = (float)(philox_u32(p.seed, p.counter, (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
+          const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+          const float u = (float)(philox_u32(p.seed, ctr, (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
           float c = 0.f;
           bool found = false;
           for (int a = 0; a < A; ++a) {
@@ -419,24 +508,31 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward kernel
+// update kernel: forward + head gradient (external | PPO actor loss | value loss) + backward
 // ------------------------------------------------------------------------------------------------
-struct BwdArgs {
+struct UpdArgs {
   const float *params, *x;
   const int32_t *rows;
-  const float *dout;
   float *slabs;
   int64_t slab_stride, slab_col0;
   mappo_net_desc desc;
   NetOff off;
   LdsMap map;
   int64_t B;
+  int n_regions;             // LDS regions of P floats used for the end-of-kernel reduction (2 when they fit)
+  // HEAD 0
+  const float *dout;
+  // HEAD 1 / 2 (buffer-order arrays, indexed by rows)
+  const float *avail, *actions, *old_logp, *adv, *active, *v_old, *returns, *vn_state;
+  const double *mb_moments;
+  double *partials;          // [gridDim.x][4]
+  mappo_ppo_cfg cfg;
 };
 
 // sum over the 32 samples of row `f` (= lane) of a [64][TP] tile
 __device__ __forceinline__ float tile_row_sum(const float *tile, int lane) {
   float s0 = 0.f, s1 = 0.f;
-#pragma unroll 8
+#pragma unroll 4
   for (int j = 0; j < TS; j += 2) { s0 += tile[lane * TP + j]; s1 += tile[lane * TP + j + 1]; }
   return s0 + s1;
 }
@@ -471,13 +567,18 @@ __device__ __forceinline__ void ln_act_backward(f32x16 (&dH)[2], float *tile, fl
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int f = 32 * t + ROWMAP(r, half);
-      tile[f * TP + l31] = dH[t][r] * xh[t][r];
-      const float dxh = dH[t][r] * sG[f];
-      dH[t][r] = dxh;
-      m1 += dxh;
-      m2 += dxh * xh[t][r];
+    for (int q = 0; q < 4; ++q) {
+      const float4 g4 = vec4_of(sG, t, q, half);
+      const float gq[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int r = 4 * q + c;
+        tile[(32 * t + ROWMAP(r, half)) * TP + l31] = dH[t][r] * xh[t][r];
+        const float dxh = dH[t][r] * gq[c];
+        dH[t][r] = dxh;
+        m1 += dxh;
+        m2 += dxh * xh[t][r];
+      }
     }
   wave_lds_sync();
   gG += tile_row_sum(tile, lane);
@@ -501,19 +602,63 @@ __device__ __forceinline__ void ln_act_backward(f32x16 (&dH)[2], float *tile, fl
   wave_lds_sync();
 }
 
-template <bool RELU, int LN>
-__global__ __launch_bounds__(256, 1) void mlp_backward_kernel(BwdArgs p) {
+// per-sample inputs of the in-kernel loss heads, prefetched one tile ahead (lanes 0..31 hold one sample each)
+struct LossPrefetch {
+  float f0, f1, f2, f3;     // actor: action, old_logp, adv, active   | critic: v_old, ret, active, -
+  uint32_t dead;            // actor: bit a set <=> available_actions[a] == 0
+};
+
+template <int HEAD, bool WIDE>
+__device__ __forceinline__ void prefetch_loss(LossPrefetch &lp, const UpdArgs &p, const RowPrefetch<WIDE> &pf, int lane, int A) {
+  lp.f0 = lp.f1 = lp.f2 = lp.f3 = 0.f;
+  lp.dead = 0u;
+  if (HEAD == 0 || lane >= pf.n_valid) return;
+  const int64_t row = pf.my_row;
+  if (HEAD == 1) {
+    lp.f0 = p.actions[row]; lp.f1 = p.old_logp[row]; lp.f2 = p.adv[row]; lp.f3 = p.active[row];
+    if (p.avail) {
+      const float *av = p.avail + row * A;
+      for (int a = 0; a < A; ++a) lp.dead |= (av[a] == 0.f ? 1u : 0u) << a;
+    }
+  } else {
+    lp.f0 = p.v_old[row]; lp.f1 = p.returns[row]; lp.f2 = p.active[row];
+  }
+}
+
+template <bool RELU, int LN, int HEAD, bool WIDE>
+__global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   extern __shared__ __align__(16) float lds[];
+  __shared__ double red_smem[16 * 4];
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
-  stage_all_weights<LN>(lds, m, p.params, o, p.desc);
-  __syncthreads();
   const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
   const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
-  const bool wide = D > 32;          // second 32-wide tile over the input features in use
+  constexpr bool wide = WIDE;        // second 32-wide tile over the input features in use
+  const int64_t n_tiles = (p.B + TS - 1) / TS;
+  const int64_t tile_stride = (int64_t)gridDim.x * n_waves;
+  int64_t tile = (int64_t)blockIdx.x * n_waves + wave;
+  RowPrefetch<WIDE> pf;
+  LossPrefetch lp;
+  prefetch_rows(pf, p.x, p.rows, tile * TS, p.B, D, lane);
+  prefetch_loss<HEAD, WIDE>(lp, p, pf, lane, A);
+  stage_all_weights<LN>(lds, m, p.params, o, p.desc);
+  __syncthreads();
   float *tX = lds + m.tiles + wave * m.wave_stride;
-  float *tH = tX + HID * TP;
+  float *tH = tX + m.x_rows * TP;
+  float *tZ = tH + (LN + 1) * HID * TP;
+
+  // loss constants (HEAD 1/2): denominators are GLOBAL (mb_moments), see ppo_loss.hip
+  float scale_pi = 0.f, scale_v = 0.f, vn_mean = 0.f, vn_sd = 1.f;
+  if (HEAD != 0) {
+    const double sa = p.mb_moments[2], Bg = p.mb_moments[3];
+    const float inv_act = (float)(1.0 / (sa > 0.0 ? sa : 1.0)), inv_B = (float)(1.0 / (Bg > 0.0 ? Bg : 1.0));
+    scale_pi = p.cfg.use_policy_active_masks ? inv_act : inv_B;
+    scale_v = p.cfg.use_value_active_masks ? inv_act : inv_B;
+    const VnStats vn = vn_stats(p.cfg.use_valuenorm ? p.vn_state : nullptr);
+    vn_mean = vn.mean; vn_sd = vn.sd;
+  }
+  double lacc[4] = {0.0, 0.0, 0.0, 0.0};   // actor: sum w*min(s1,s2), sum w*H, sum ratio | critic: sum w_v*l
 
   // ---- gradient accumulators (registers, live across the tile loop) ----
   f32x16 gWh[2], gW2[LN > 0 ? LN : 1][2][2], gW1[2][2];
@@ -535,19 +680,107 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_kernel(BwdArgs p) {
 #pragma unroll
   for (int l = 0; l <= LN; ++l) { gB[l] = 0.f; gLnW[l] = 0.f; gLnB[l] = 0.f; }
 
-  const int64_t n_tiles = (p.B + TS - 1) / TS;
-  for (int64_t tile = (int64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * n_waves) {
+  for (; tile < n_tiles; tile += tile_stride) {
     const int64_t base = tile * TS;
-    const int n_valid = (int)min((int64_t)TS, p.B - base);
-    gather_tile(tX, p.x, p.rows, base, n_valid, D, Dp, lane);
+    const int n_valid = pf.n_valid;
+    const LossPrefetch cur = lp;
+    commit_rows(tX, pf, Dp, lane);
     wave_lds_sync();
-    feature_norm_tile(tX, D, Dp, l31, half, p.desc.use_feature_norm != 0);
+    prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);   // next tile, hidden under the MFMAs below
+    prefetch_loss<HEAD, WIDE>(lp, p, pf, lane, A);
+    feature_norm_tile(tX, D, l31, half, p.desc.use_feature_norm != 0);
     wave_lds_sync();
     TileStats<LN> st;
     tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
     float *tLast = tH + LN * HID * TP;
 
-    // ---- (A) head weight / bias gradients:  dWh[a][f] += sum_s dout[s][a] * h_last[f][s] ----
+    // ---- head gradient into tZ[s][a] ----
+    if (HEAD == 0) {
+      for (int e = lane; e < TS * A; e += WAVE) {
+        const int s = e / A, a = e - s * A;
+        tZ[s * TP + a] = (s < n_valid) ? p.dout[base * A + e] : 0.f;
+      }
+    } else {
+      const f32x16 z = head_forward(lds, m, tLast, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN), l31, half);
+      if (HEAD == 1) {
+        head_to_tile(tZ, z, A, l31, half);
+        wave_lds_sync();
+        if (lane < TS) {
+          float *zl = tZ + lane * TP;
+          if (lane < n_valid) {
+            // distributions.py:64-68 + r_mappo.py:124-141 (same arithmetic as ppo_loss.hip)
+            const int act = (int)cur.f0;
+            const float old_lp = cur.f1, adv = cur.f2, active = cur.f3, clip = p.cfg.clip_param;
+            float zmax = -FLT_MAX;
+            for (int a = 0; a < A; ++a) {
+              float za = zl[a];
+              if (cur.dead & (1u << a)) { za = -1e10f; zl[a] = za; }
+              zmax = fmaxf(zmax, za);
+            }
+            float se = 0.f;
+            for (int a = 0; a < A; ++a) se += expf(zl[a] - zmax);
+            const float lse = zmax + logf(se);
+            float Hent = 0.f;
+            for (int a = 0; a < A; ++a) { const float l_ = zl[a] - lse; Hent -= expf(l_) * fmaxf(l_, -FLT_MAX); }
+            const float logp = zl[act] - lse;
+            const float ratio = expf(logp - old_lp);
+            const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * adv;
+            const float w_pi = p.cfg.use_policy_active_masks ? active : 1.f;
+            const float dlogp = (s1 <= s2) ? -(w_pi * scale_pi) * adv * ratio : 0.f;
+            const float ce = p.cfg.entropy_coef * w_pi * scale_pi;
+            for (int a = 0; a < A; ++a) {
+              const float l_ = zl[a] - lse, pa = expf(l_);
+              float g = dlogp * ((a == act ? 1.f : 0.f) - pa) + ce * pa * (l_ + Hent);
+              if (cur.dead & (1u << a)) g = 0.f;
+              zl[a] = g;
+            }
+            lacc[0] += (double)(w_pi * fminf(s1, s2));
+            lacc[1] += (double)(w_pi * Hent);
+            lacc[2] += (double)ratio;
+          } else {
+            for (int a = 0; a < A; ++a) zl[a] = 0.f;
+          }
+        }
+      } else {
+        // value loss (r_mappo.py:62-87); the value of sample s is register 0 of lane s (half 0)
+        if (lane < TS) {
+          float dvv = 0.f;
+          if (lane < n_valid) {
+            const float v = z[0], vo = cur.f0, ret = cur.f1, active = cur.f2, clip = p.cfg.clip_param;
+            const float tgt = p.cfg.use_valuenorm ? (ret - vn_mean) / vn_sd : ret;
+            const float dvc = fminf(fmaxf(v - vo, -clip), clip);
+            const float e_o = tgt - v, e_c = tgt - (vo + dvc);
+            float l_o, l_c, g_o, g_c;
+            if (p.cfg.use_huber_loss) {
+              const float dl = p.cfg.huber_delta;
+              const bool so = fabsf(e_o) <= dl, sc = fabsf(e_c) <= dl;
+              l_o = so ? e_o * e_o * 0.5f : dl * (fabsf(e_o) - dl * 0.5f);
+              l_c = sc ? e_c * e_c * 0.5f : dl * (fabsf(e_c) - dl * 0.5f);
+              g_o = so ? e_o : copysignf(dl, e_o);
+              g_c = sc ? e_c : copysignf(dl, e_c);
+            } else {
+              l_o = e_o * e_o * 0.5f; l_c = e_c * e_c * 0.5f; g_o = e_o; g_c = e_c;
+            }
+            float l, dv;
+            if (p.cfg.use_clipped_value_loss) {
+              const float inside = (fabsf(v - vo) <= clip) ? 1.f : 0.f;
+              const float d_o = -g_o, d_c = -g_c * inside;
+              l = fmaxf(l_o, l_c);
+              dv = (l_o > l_c) ? d_o : ((l_c > l_o) ? d_c : 0.5f * (d_o + d_c));
+            } else {
+              l = l_o; dv = -g_o;
+            }
+            const float w_v = p.cfg.use_value_active_masks ? active : 1.f;
+            dvv = dv * (w_v * scale_v) * p.cfg.value_loss_coef;
+            lacc[0] += (double)(w_v * l);
+          }
+          tZ[lane * TP] = dvv;
+        }
+      }
+    }
+    wave_lds_sync();
+
+    // ---- (A) head weight / bias gradients:  dWh[a][f] += sum_s dz[s][a] * h_last[f][s] ----
     {
       const float *sG = lds + ln_w_of<LN>(m, LN), *sBt = lds + ln_b_of<LN>(m, LN);
       const float g0 = sG[l31], c0 = sBt[l31], g1 = sG[32 + l31], c1 = sBt[32 + l31];
@@ -555,15 +788,14 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_kernel(BwdArgs p) {
 #pragma unroll 2
       for (int ss = 0; ss < TS / 2; ++ss) {
         const int s = 2 * ss + half;
-        float av = 0.f;
-        if (l31 < A && s < n_valid) av = p.dout[(base + s) * A + l31];
+        const float av = (l31 < A) ? tZ[s * TP + l31] : 0.f;
         bsum += av;
         gWh[0] = mfma(av, tLast[l31 * TP + s] * g0 + c0, gWh[0]);
         gWh[1] = mfma(av, tLast[(32 + l31) * TP + s] * g1 + c1, gWh[1]);
       }
       gBh += xhalf_sum(bsum);
     }
-    // ---- (B) d h_last = Wh^T . dout ----
+    // ---- (B) d h_last = Wh^T . dz ----
     f32x16 dH[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -573,8 +805,7 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_kernel(BwdArgs p) {
       const float *sW = lds + m.wh;
       for (int kk = 0; kk < (A + 1) / 2; ++kk) {
         const int a = 2 * kk + half;
-        float b = 0.f;
-        if (a < A && l31 < n_valid) b = p.dout[(base + l31) * A + a];
+        const float b = (a < A) ? tZ[l31 * TP + a] : 0.f;
         dH[0] = mfma(sW[l31 * HP + a], b, dH[0]);
         dH[1] = mfma(sW[(32 + l31) * HP + a], b, dH[1]);
       }
@@ -682,13 +913,24 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_kernel(BwdArgs p) {
     }
   }
 
-  // ---- reduce the waves' accumulators through LDS and write this workgroup's slab ----
+  // ---- loss statistics of this workgroup ----
+  if (HEAD != 0) {
+    block_sum<4>(lacc, red_smem);
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) p.partials[(size_t)blockIdx.x * 4 + k] = lacc[k];
+    }
+  }
+
+  // ---- reduce the waves' accumulators through LDS (two regions, waves pair up) and write the slab ----
   __syncthreads();
-  float *red = lds + m.tiles;                      // >= P floats (checked on the host)
   const int P = o.total;
-  for (int w = 0; w < n_waves; ++w) {
-    if (wave == w) {
-      const bool first = (w == 0);
+  float *red0 = lds + m.tiles;                     // n_regions * P floats fit in the tile area (checked on the host)
+  const int n_reg = p.n_regions;
+  for (int round = 0; round < (n_waves + n_reg - 1) / n_reg; ++round) {
+    if (wave / n_reg == round) {
+      float *red = red0 + (wave % n_reg) * P;
+      const bool first = (round == 0);
 #define RED(idx, val) do { const int i_ = (idx); if (first) red[i_] = (val); else red[i_] += (val); } while (0)
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
@@ -722,7 +964,11 @@ __global__ __launch_bounds__(256, 1) void mlp_backward_kernel(BwdArgs p) {
     __syncthreads();
   }
   float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
-  for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red[e];
+  if (n_reg > 1) {
+    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red0[e] + red0[P + e];
+  } else {
+    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red0[e];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -742,47 +988,50 @@ static int check_desc(const mappo_net_desc *d, const char *who) {
 }
 
 #define LDS_LIMIT (160 * 1024)
+#define LDS_STATIC 1024                      // static __shared__ of the kernels (reduction scratch), rounded up
+#define LDS_DYN_MAX (LDS_LIMIT - LDS_STATIC) // what hipFuncAttributeMaxDynamicSharedMemorySize may be raised to
 #define NUM_CU 256
 
-static int pick_waves(const mappo_net_desc &d, int tiles_per_wave, int64_t n_tiles) {
-  int nw = 4;
-  while (nw > 1 && (size_t)lds_map(d, nw, tiles_per_wave).total * sizeof(float) > LDS_LIMIT) nw >>= 1;
-  // few tiles (rollout-sized batches): one wave per workgroup spreads them over more CUs
-  while (nw > 1 && n_tiles < (int64_t)NUM_CU * nw) nw >>= 1;
+static int fit_waves(const mappo_net_desc &d, int want) {
+  int nw = want;
+  while (nw > 1 && (size_t)lds_map(d, nw).total * sizeof(float) > LDS_DYN_MAX) nw >>= 1;
   return nw;
 }
 
 template <int MODE>
 static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) {
+  MAPPO_CLEAR_STICKY();
   const int64_t n_tiles = (a_in.B + TS - 1) / TS;
   const int LN = a_in.desc.layer_N;
-  const int nw = pick_waves(a_in.desc, LN + 2, n_tiles);
+  // all waves of a workgroup stage the weights together, so 4 waves per workgroup even for rollout-sized batches
+  const int nw = fit_waves(a_in.desc, n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1));
   FwdArgs a = a_in;
   a.off = net_offsets(a.desc);
-  a.map = lds_map(a.desc, nw, LN + 2);
+  a.map = lds_map(a.desc, nw);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
-  MAPPO_REQUIRE(lds_bytes <= LDS_LIMIT, "%s: needs %zu B of LDS", who, lds_bytes);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
   int64_t nb = (n_tiles + nw - 1) / nw;
   if (nb > NUM_CU) nb = NUM_CU;
   dim3 grid((unsigned)nb), block(WAVE * nw);
-#define FWD(R, L)                                                                                              \
+#define FWD2(R, L, W)                                                                                          \
   do {                                                                                                         \
-    static size_t attr_set = 0;                                                                                \
-    if (attr_set < lds_bytes) {                                                                                \
-      (void)hipFuncSetAttribute((const void *)mlp_forward_kernel<R, L, MODE>,                                   \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);                   \
-      attr_set = LDS_LIMIT;                                                                                    \
+    static bool attr_set = false;                                                                              \
+    if (!attr_set) {                                                                                           \
+      hipError_t e_ = hipFuncSetAttribute((const void *)mlp_forward_kernel<R, L, MODE, W>,                      \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);       \
+      if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; } \
+      attr_set = true;                                                                                         \
     }                                                                                                          \
-    hipLaunchKernelGGL((mlp_forward_kernel<R, L, MODE>), grid, block, lds_bytes, st, a);                        \
+    PROF_LAUNCH(prof_id, (mlp_forward_kernel<R, L, MODE, W>), grid, block, lds_bytes, st, a);                   \
   } while (0)
-  const bool relu = a.desc.use_relu != 0;
+#define FWD_W(R, L) do { if (wide) FWD2(R, L, true); else FWD2(R, L, false); } while (0)
+  const bool relu = a.desc.use_relu != 0, wide = a.desc.in_dim > 32;
   const int prof_id = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
-  PROF_BEGIN(prof_id, st);
-  if (LN == 0) { if (relu) FWD(true, 0); else FWD(false, 0); }
-  else if (LN == 1) { if (relu) FWD(true, 1); else FWD(false, 1); }
-  else { if (relu) FWD(true, 2); else FWD(false, 2); }
-  PROF_END(prof_id, st);
-#undef FWD
+  if (LN == 0) { if (relu) FWD_W(true, 0); else FWD_W(false, 0); }
+  else if (LN == 1) { if (relu) FWD_W(true, 1); else FWD_W(false, 1); }
+  else { if (relu) FWD_W(true, 2); else FWD_W(false, 2); }
+#undef FWD_W
+#undef FWD2
   MAPPO_CHECK_LAUNCH(who);
   return MAPPO_OK;
 }
@@ -797,26 +1046,57 @@ extern "C" int mappo_mlp_forward(const float *params, const mappo_net_desc *desc
 }
 
 extern "C" int mappo_actor_act(const float *params, const mappo_net_desc *desc, const float *obs, const float *avail,
-                               int64_t B, int32_t deterministic, uint64_t seed, uint64_t counter, float *actions,
-                               float *logp, mappo_stream_t stream) {
+                               int64_t B, int32_t deterministic, uint64_t seed, uint64_t counter,
+                               const uint64_t *counter_dev, float *actions, float *logp, mappo_stream_t stream) {
   if (int rc = check_desc(desc, "actor_act")) return rc;
   MAPPO_REQUIRE(params && obs && actions && logp && B > 0, "actor_act: bad arguments");
   FwdArgs a = {};
   a.params = params; a.x = obs; a.rows = nullptr; a.avail = avail; a.actions = actions; a.logp = logp; a.desc = *desc;
-  a.B = B; a.deterministic = deterministic; a.seed = seed; a.counter = counter;
+  a.B = B; a.deterministic = deterministic; a.seed = seed; a.counter = counter; a.counter_dev = counter_dev;
   return launch_forward<1>(a, as_stream(stream), "actor_act");
 }
 
-static int bwd_waves(const mappo_net_desc &d) {
-  int nw = 4;
-  while (nw > 1 && (size_t)lds_map(d, nw, d.layer_N + 2).total * sizeof(float) > LDS_LIMIT) nw >>= 1;
-  return nw;
-}
-
 extern "C" int32_t mappo_mlp_backward_slabs(int64_t B) {
-  // upper bound used to size the slab buffer: one slab per workgroup, at most one workgroup per CU
+  // number of slabs an update/backward launch writes: one per workgroup, at most one workgroup per CU
   int64_t n_tiles = (B + TS - 1) / TS;
   return (int32_t)(n_tiles < NUM_CU ? n_tiles : NUM_CU);
+}
+
+template <int HEAD>
+static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
+  MAPPO_CLEAR_STICKY();
+  const mappo_net_desc &d = a.desc;
+  a.off = net_offsets(d);
+  MAPPO_REQUIRE(a.slab_col0 >= 0 && a.slab_col0 + a.off.total <= a.slab_stride, "%s: slab column range", who);
+  const int LN = d.layer_N;
+  const int nw = fit_waves(d, 4);
+  a.map = lds_map(d, nw);
+  const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
+  a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * a.off.total) ? 2 : 1;
+  MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * a.off.total, "%s: reduction buffer too small", who);
+  const int nb = mappo_mlp_backward_slabs(a.B);    // every slab the caller sized for is written: grid == that count
+  dim3 grid((unsigned)nb), block(WAVE * nw);
+#define UPD2(R, L, W)                                                                                      \
+  do {                                                                                                     \
+    static bool attr_set = false;                                                                          \
+    if (!attr_set) {                                                                                       \
+      hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update_kernel<R, L, HEAD, W>,                   \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);   \
+      if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; } \
+      attr_set = true;                                                                                     \
+    }                                                                                                      \
+    PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update_kernel<R, L, HEAD, W>), grid, block, lds_bytes, st, a);     \
+  } while (0)
+#define UPD(R, L) do { if (wide) UPD2(R, L, true); else UPD2(R, L, false); } while (0)
+  const bool relu = d.use_relu != 0, wide = d.in_dim > 32;
+  if (LN == 0) { if (relu) UPD(true, 0); else UPD(false, 0); }
+  else if (LN == 1) { if (relu) UPD(true, 1); else UPD(false, 1); }
+  else { if (relu) UPD(true, 2); else UPD(false, 2); }
+#undef UPD
+#undef UPD2
+  MAPPO_CHECK_LAUNCH(who);
+  return MAPPO_OK;
 }
 
 extern "C" int mappo_mlp_backward(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
@@ -824,39 +1104,76 @@ extern "C" int mappo_mlp_backward(const float *params, const mappo_net_desc *des
                                   mappo_stream_t stream) {
   if (int rc = check_desc(desc, "mlp_backward")) return rc;
   MAPPO_REQUIRE(params && x && dout && slabs && B > 0, "mlp_backward: bad arguments");
-  const NetOff o = net_offsets(*desc);
-  MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + o.total <= slab_stride, "mlp_backward: slab column range");
-  const int LN = desc->layer_N;
-  const int nw = bwd_waves(*desc);
-  const LdsMap m = lds_map(*desc, nw, LN + 2);
-  const size_t lds_bytes = (size_t)m.total * sizeof(float);
-  MAPPO_REQUIRE(lds_bytes <= LDS_LIMIT, "mlp_backward: needs %zu B of LDS", lds_bytes);
-  MAPPO_REQUIRE(nw * m.wave_stride >= o.total, "mlp_backward: reduction buffer smaller than the parameter count");
-  // every slab the caller sized for (mappo_mlp_backward_slabs) must be written: grid == that count
-  const int nb = mappo_mlp_backward_slabs(B);
-  BwdArgs a;
+  UpdArgs a = {};
   a.params = params; a.x = x; a.rows = rows; a.dout = dout; a.slabs = slabs; a.slab_stride = slab_stride;
-  a.slab_col0 = slab_col0; a.desc = *desc; a.B = B; a.off = o; a.map = m;
-  dim3 grid((unsigned)nb), block(WAVE * nw);
-  hipStream_t st = as_stream(stream);
-#define BWD(R, L)                                                                                          \
-  do {                                                                                                     \
-    static size_t attr_set = 0;                                                                            \
-    if (attr_set < lds_bytes) {                                                                            \
-      (void)hipFuncSetAttribute((const void *)mlp_backward_kernel<R, L>,                                    \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT);               \
-      attr_set = LDS_LIMIT;                                                                                \
-    }                                                                                                      \
-    hipLaunchKernelGGL((mlp_backward_kernel<R, L>), grid, block, lds_bytes, st, a);                         \
-  } while (0)
-  const bool relu = desc->use_relu != 0;
-  PROF_BEGIN(MAPPO_PROF_MLP_BWD, st);
-  if (LN == 0) { if (relu) BWD(true, 0); else BWD(false, 0); }
-  else if (LN == 1) { if (relu) BWD(true, 1); else BWD(false, 1); }
-  else { if (relu) BWD(true, 2); else BWD(false, 2); }
-  PROF_END(MAPPO_PROF_MLP_BWD, st);
-#undef BWD
-  MAPPO_CHECK_LAUNCH("mlp_backward");
+  a.slab_col0 = slab_col0; a.desc = *desc; a.B = B;
+  return launch_update<0>(a, as_stream(stream), "mlp_backward");
+}
+
+extern "C" int64_t mappo_update_partials_bytes(void) { return (int64_t)NUM_CU * 4 * sizeof(double); }
+
+extern "C" int mappo_actor_update(const float *params, const mappo_net_desc *desc, const float *obs, const int32_t *rows,
+                                  int64_t B, const float *avail, const float *actions, const float *old_logp,
+                                  const float *adv, const float *active, const double *mb_moments,
+                                  const mappo_ppo_cfg *cfg, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                                  double *partials, mappo_stream_t stream) {
+  if (int rc = check_desc(desc, "actor_update")) return rc;
+  MAPPO_REQUIRE(params && obs && actions && old_logp && adv && active && mb_moments && cfg && slabs && partials && B > 0,
+                "actor_update: bad arguments");
+  UpdArgs a = {};
+  a.params = params; a.x = obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
+  a.desc = *desc; a.B = B; a.avail = avail; a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.active = active;
+  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg;
+  return launch_update<1>(a, as_stream(stream), "actor_update");
+}
+
+extern "C" int mappo_critic_update(const float *params, const mappo_net_desc *desc, const float *share_obs,
+                                   const int32_t *rows, int64_t B, const float *v_old, const float *returns,
+                                   const float *active, const float *vn_state, const double *mb_moments,
+                                   const mappo_ppo_cfg *cfg, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                                   double *partials, mappo_stream_t stream) {
+  if (int rc = check_desc(desc, "critic_update")) return rc;
+  MAPPO_REQUIRE(desc->out_dim == 1, "critic_update: out_dim must be 1");
+  MAPPO_REQUIRE(params && share_obs && v_old && returns && active && mb_moments && cfg && slabs && partials && B > 0,
+                "critic_update: bad arguments");
+  MAPPO_REQUIRE(!cfg->use_valuenorm || vn_state, "critic_update: use_valuenorm needs vn_state");
+  UpdArgs a = {};
+  a.params = params; a.x = share_obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
+  a.desc = *desc; a.B = B; a.v_old = v_old; a.returns = returns; a.active = active; a.vn_state = vn_state;
+  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg;
+  return launch_update<2>(a, as_stream(stream), "critic_update");
+}
+
+// statistics of one fused update from the two kernels' per-workgroup partial sums (same layout as
+// mappo_ppo_loss_fwd_bwd's `stats`)
+__global__ __launch_bounds__(256) void update_stats_kernel(const double *__restrict__ pa, const double *__restrict__ pc, int na,
+                                                          int nc, const double *__restrict__ mb_moments, int use_policy_active,
+                                                          int use_value_active, double *__restrict__ stats) {
+  __shared__ double smem[16 * 4];
+  double v[4] = {0.0, 0.0, 0.0, 0.0};    // sum w*min, sum w*H, sum ratio, sum w_v*l
+  for (int b = threadIdx.x; b < na; b += blockDim.x) { v[0] += pa[b * 4 + 0]; v[1] += pa[b * 4 + 1]; v[2] += pa[b * 4 + 2]; }
+  for (int b = threadIdx.x; b < nc; b += blockDim.x) v[3] += pc[b * 4 + 0];
+  block_sum<4>(v, smem);
+  if (threadIdx.x == 0) {
+    const double sa = mb_moments[2] > 0.0 ? mb_moments[2] : 1.0;
+    const double Bg = mb_moments[3] > 0.0 ? mb_moments[3] : 1.0;
+    const double den_pi = use_policy_active ? sa : Bg, den_v = use_value_active ? sa : Bg;
+    stats[0] = v[3] / den_v;
+    stats[1] = -v[0] / den_pi;
+    stats[2] = v[1] / den_pi;
+    stats[3] = v[2] / Bg;
+    stats[4] = mb_moments[2];
+    stats[5] = mb_moments[3];
+  }
+}
+
+extern "C" int mappo_update_stats(const double *actor_partials, const double *critic_partials, int64_t B,
+                                  const double *mb_moments, const mappo_ppo_cfg *cfg, double *stats, mappo_stream_t stream) {
+  MAPPO_REQUIRE(critic_partials && mb_moments && cfg && stats && B > 0, "update_stats: bad arguments");
+  const int nb = mappo_mlp_backward_slabs(B);
+  hipLaunchKernelGGL(update_stats_kernel, dim3(1), dim3(256), 0, as_stream(stream), actor_partials, critic_partials,
+                     actor_partials ? nb : 0, nb, mb_moments, cfg->use_policy_active_masks, cfg->use_value_active_masks, stats);
+  MAPPO_CHECK_LAUNCH("update_stats");
   return MAPPO_OK;
 }
 

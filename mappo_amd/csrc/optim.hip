@@ -112,10 +112,8 @@ extern "C" int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t sl
                                  mappo_stream_t stream) {
   MAPPO_REQUIRE(slabs && grad && n_slabs > 0 && P > 0 && slab_stride >= P, "slab_reduce: bad arguments");
   const int nblk = (int)((P + OPT_BLOCK - 1) / OPT_BLOCK);
-  PROF_BEGIN(MAPPO_PROF_SLAB_REDUCE, as_stream(stream));
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, as_stream(stream), slabs, (int)n_slabs,
-                     slab_stride, P, grad);
-  PROF_END(MAPPO_PROF_SLAB_REDUCE, as_stream(stream));
+  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, as_stream(stream), slabs,
+              (int)n_slabs, slab_stride, P, grad);
   MAPPO_CHECK_LAUNCH("slab_reduce");
   return MAPPO_OK;
 }

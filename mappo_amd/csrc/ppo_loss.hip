@@ -210,9 +210,7 @@ extern "C" int mappo_ppo_loss_fwd_bwd(const float *logits, const float *values, 
   p.dlogits = dlogits; p.dvalues = dvalues; p.partials = (double *)workspace; p.cfg = *cfg; p.B = B; p.A = A;
   const int nblk = pl_blocks(B);
   const size_t lds = (size_t)PL_BLOCK * A * sizeof(float);
-  PROF_BEGIN(MAPPO_PROF_PPO_LOSS, as_stream(stream));
-  hipLaunchKernelGGL(ppo_loss_kernel, dim3(nblk), dim3(PL_BLOCK), lds, as_stream(stream), p);
-  PROF_END(MAPPO_PROF_PPO_LOSS, as_stream(stream));
+  PROF_LAUNCH(MAPPO_PROF_PPO_LOSS, ppo_loss_kernel, dim3(nblk), dim3(PL_BLOCK), lds, as_stream(stream), p);
   hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(PL_BLOCK), 0, as_stream(stream), (const double *)workspace, nblk,
                      mb_moments, B, cfg->use_policy_active_masks, cfg->use_value_active_masks, stats);
   MAPPO_CHECK_LAUNCH("ppo_loss_fwd_bwd");

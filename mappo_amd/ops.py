@@ -116,10 +116,10 @@ def mlp_forward(params, desc, x, rows, B, out):
     _lib.check(rc, "mappo_mlp_forward")
 
 
-def actor_act(params, desc, obs, avail, B, deterministic, seed, counter, actions, logp):
+def actor_act(params, desc, obs, avail, B, deterministic, seed, counter, actions, logp, counter_dev=None):
     rc = _lib.load().mappo_actor_act(_ptr(params), C.byref(desc), _ptr(obs), _ptr(avail, allow_none=True), int(B),
                                      int(bool(deterministic)), int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
-                                     _ptr(actions), _ptr(logp), _stream())
+                                     _ptr(counter_dev, torch.int64, allow_none=True), _ptr(actions), _ptr(logp), _stream())
     _lib.check(rc, "mappo_actor_act")
 
 
@@ -131,6 +131,35 @@ def mlp_backward(params, desc, x, rows, B, dout, slabs, slab_stride, slab_col0):
     rc = _lib.load().mappo_mlp_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True),
                                         int(B), _ptr(dout), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
     _lib.check(rc, "mappo_mlp_backward")
+
+
+# ---- fused update kernels ------------------------------------------------------------------------
+def update_partials(device):
+    return torch.zeros(int(_lib.load().mappo_update_partials_bytes()) // 8, dtype=torch.float64, device=device)
+
+
+def actor_update(params, desc, obs, rows, B, avail, actions, old_logp, adv, active, mb_moments, cfg, slabs, slab_stride,
+                 slab_col0, partials):
+    rc = _lib.load().mappo_actor_update(_ptr(params), C.byref(desc), _ptr(obs), _ptr(rows, torch.int32, allow_none=True), int(B),
+                                        _ptr(avail, allow_none=True), _ptr(actions), _ptr(old_logp), _ptr(adv), _ptr(active),
+                                        _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(slabs), int(slab_stride),
+                                        int(slab_col0), _ptr(partials, torch.float64), _stream())
+    _lib.check(rc, "mappo_actor_update")
+
+
+def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_state, mb_moments, cfg, slabs, slab_stride,
+                  slab_col0, partials):
+    rc = _lib.load().mappo_critic_update(_ptr(params), C.byref(desc), _ptr(share_obs), _ptr(rows, torch.int32, allow_none=True),
+                                         int(B), _ptr(v_old), _ptr(returns), _ptr(active), _ptr(vn_state, allow_none=True),
+                                         _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(slabs), int(slab_stride),
+                                         int(slab_col0), _ptr(partials, torch.float64), _stream())
+    _lib.check(rc, "mappo_critic_update")
+
+
+def update_stats(actor_partials, critic_partials, B, mb_moments, cfg, stats):
+    rc = _lib.load().mappo_update_stats(_ptr(actor_partials, torch.float64, allow_none=True), _ptr(critic_partials, torch.float64),
+                                        int(B), _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(stats, torch.float64), _stream())
+    _lib.check(rc, "mappo_update_stats")
 
 
 # ---- K10 / K11 ------------------------------------------------------------------------------------

@@ -118,9 +118,7 @@ class Runner(object):
     # base_runner.py:120-125
     def train(self):
         self.trainer.prep_training()
-        train_infos = self.trainer.train(self.buffer)
-        self.buffer.after_update()
-        return train_infos
+        return self.trainer.train(self.buffer, after_update=True)     # buffer.after_update() runs inside (same order)
 
     # base_runner.py:127-135
     def save(self):

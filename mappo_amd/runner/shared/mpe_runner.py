@@ -17,6 +17,9 @@ class MPERunner(Runner):
     def __init__(self, config):
         super(MPERunner, self).__init__(config)
         self._onehot = None
+        self._rollout_graph = None          # None -> "warm" -> CUDAGraph
+        self._use_graph = bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False)) \
+            and config.get("dist_group") is None
 
     def run(self):
         self.warmup()
@@ -49,14 +52,38 @@ class MPERunner(Runner):
         """One iteration of the hot loop (mpe_runner.py:22-40): T x (collect, env.step, insert), compute, train."""
         if self.use_linear_lr_decay:
             self.trainer.policy.lr_decay(episode, episodes)
+        infos = self.rollout()
+        return self.train(), infos
+
+    def _rollout_body(self):
         infos = None
+        self.trainer.policy.actor._counter_dev.add_(self.episode_length)   # fresh sampling stream per (replayed) episode
         for step in range(self.episode_length):
             values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env = self.collect(step)
             obs, rewards, dones, infos = self.envs.step(actions_env)
             data = obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic
             self.insert(data)
         self.compute()
-        return self.train(), infos
+        return infos
+
+    def rollout(self):
+        """T x (collect, env.step, insert) + compute().  With a vec-env that declares `graph_safe` (device-resident,
+        no host control flow that depends on data: mappo_amd.envs.synthetic) the episode is captured into one
+        hipGraph after a first eager pass and replayed; any other env runs eagerly, step by step."""
+        if not self._use_graph:
+            return self._rollout_body()
+        if self._rollout_graph is None:
+            infos = self._rollout_body()
+            self._rollout_graph = "warm"
+            return infos
+        if self._rollout_graph == "warm":
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._rollout_body()
+            self._rollout_graph = g
+        self._rollout_graph.replay()
+        return None
 
     # mpe_runner.py:81-93
     def warmup(self):

@@ -166,7 +166,8 @@ def test_reference_seeded_init_matches(M):
         close(v, d[f"critic0/{k}"], 1e-5, 2e-5, k)
 
 
-def test_ppo_update_golden_variants(M):
+@pytest.mark.parametrize("unfused", [False, True])
+def test_ppo_update_golden_variants(M, unfused):
     """R_MAPPO.ppo_update on the reference's own sample tuples: the 6 returned statistics, post-step
     parameters, Adam moments and ValueNorm state (all MLP cases of the fixture that the kernels are tiled for)."""
     g = golden("ppo_update")
@@ -180,7 +181,7 @@ def test_ppo_update_golden_variants(M):
         hy = d["hyper"]
         a = make_args(M, episode_length=T, n_rollout_threads=N, hidden_size=H, clip_param=float(hy[0]), entropy_coef=float(hy[1]),
                       value_loss_coef=float(hy[2]), huber_delta=float(hy[3]), max_grad_norm=float(hy[4]), lr=float(hy[5]),
-                      critic_lr=float(hy[6]), opti_eps=float(hy[7]), weight_decay=float(hy[8]),
+                      critic_lr=float(hy[6]), opti_eps=float(hy[7]), weight_decay=float(hy[8]), unfused_update=unfused,
                       **{k: v for k, v in fl.items() if k not in ("update_actor", "two_steps", "use_recurrent_policy")})
         pol = load_policy(M, a, g, f"c{c}", D, S, A)
         tr = M.R_MAPPO(a, pol)
@@ -215,8 +216,8 @@ def test_ppo_update_small_hidden_rejected(M):
         M.R_MAPPOPolicy(a, [18], [54], M.Discrete(5))
 
 
-@pytest.mark.parametrize("case", [0, 2])
-def test_train_golden_end_to_end(M, case):
+@pytest.mark.parametrize("case,unfused", [(0, False), (2, False), (0, True)])
+def test_train_golden_end_to_end(M, case, unfused):
     """R_MAPPO.train on the reference's buffer: train_info and final parameters after ppo_epoch x num_mini_batch
     updates.  case 0: num_mini_batch=2 with the reference's CPU permutation stream (perm_device='cpu');
     case 2: num_mini_batch=1, default in-place streaming (no gather) — must equal the permuted reference run."""
@@ -224,7 +225,7 @@ def test_train_golden_end_to_end(M, case):
     d = sub(g, f"c{case}")
     T, N, Ma, D, S, A, H, nmb, rec, epochs, L = [int(x) for x in d["dims"]]
     a = make_args(M, episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=epochs, num_mini_batch=nmb,
-                  perm_device="cpu")
+                  perm_device="cpu", unfused_update=unfused)
     pol = load_policy(M, a, g, f"c{case}", D, S, A)
     tr = M.R_MAPPO(a, pol)
     buf = M.SharedReplayBuffer(a, Ma, [D], [S], M.Discrete(A))
@@ -252,27 +253,55 @@ def test_train_golden_end_to_end(M, case):
         close(pol2.flat_params, pol.flat_params, 1e-4, 5e-6)
 
 
-def test_runner_iteration_vs_oracle(M):
+def _oracle_twin(runner, oa, D, S, A):
+    """Oracle policy / ValueNorm with the runner's current weights, Adam moments and normaliser state."""
+    opol = O.PolicyRef(oa, D, S, A)
+    pol = runner.policy
+    for net, onet, opt, seg in ((pol.actor, opol.actor, opol.actor_optimizer, 0), (pol.critic, opol.critic, opol.critic_optimizer, 1)):
+        onet.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+        step = int(pol.opt_step[seg])
+        if step > 0:
+            lo = pol.seg_bounds[seg]
+            named = dict(onet.named_parameters())
+            for key, off, shape in net.layout:
+                n = int(np.prod(shape))
+                opt.state[named[key]] = dict(step=torch.tensor(float(step)),
+                                             exp_avg=pol.exp_avg[lo + off: lo + off + n].view(shape).cpu().clone(),
+                                             exp_avg_sq=pol.exp_avg_sq[lo + off: lo + off + n].view(shape).cpu().clone())
+    ovn = O.ValueNormRef()
+    ovn.load_state(runner.trainer.value_normalizer.state.cpu().numpy())
+    return opol, ovn
+
+
+@pytest.mark.parametrize("n_warm,use_graph", [(0, True), (2, True), (2, False)])
+def test_runner_iteration_vs_oracle(M, n_warm, use_graph):
     """Whole iteration at BASELINE config-1 shape (N=8, T=25, M=3): our MPERunner collects with its own sampled
     actions; the oracle then recomputes get_actions' log-probs / values on the same observations, bootstrap + GAE
-    and the full train() from the same weights and buffer — covers collect_into, insert_env, compute, train."""
+    and the full train() from the same weights / Adam state / buffer — covers collect_into, insert_env, compute,
+    train.  n_warm=2 with graphs: the compared rollout and train() are hipGraph REPLAYS (eager -> capture -> replay)."""
     T, N, Ma, D, A = 25, 8, 3, 18, 5
-    a = make_args(M, episode_length=T, n_rollout_threads=N, ppo_epoch=3, lr=7e-4, critic_lr=7e-4, seed=1, env_name="MPE")
+    a = make_args(M, episode_length=T, n_rollout_threads=N, ppo_epoch=3, lr=7e-4, critic_lr=7e-4, seed=1, env_name="MPE",
+                  use_hip_graph=use_graph)
     torch.manual_seed(1)
     env = M.SyntheticMPEEnv(N, Ma, D, A, T, seed=1)
     runner = M.MPERunner(dict(all_args=a, envs=env, eval_envs=None, num_agents=Ma, device=torch.device("cuda"), run_dir=None))
-    # oracle twin with identical weights
     oa = O.default_args(episode_length=T, n_rollout_threads=N, ppo_epoch=3, lr=7e-4, critic_lr=7e-4)
-    opol = O.PolicyRef(oa, D, D * Ma, A)
-    opol.actor.load_state_dict({k: v.cpu() for k, v in runner.policy.actor.state_dict().items()})
-    opol.critic.load_state_dict({k: v.cpu() for k, v in runner.policy.critic.state_dict().items()})
     runner.warmup()
-    for step in range(T):
-        values, actions, logp, rs, rc, actions_env = runner.collect(step)
-        obs, rewards, dones, infos = env.step(actions_env)
-        runner.insert((obs, rewards, dones, infos, values, actions, logp, rs, rc))
+    prev_obs = None
+    for _ in range(n_warm):
+        runner.run_episode()
+        cur = runner.buffer.obs[1:].clone()
+        assert prev_obs is None or not torch.equal(cur, prev_obs)           # every (replayed) episode sees fresh data
+        prev_obs = cur
+    if use_graph and n_warm >= 2:
+        assert isinstance(runner._rollout_graph, torch.cuda.CUDAGraph)
+        assert any(isinstance(g, torch.cuda.CUDAGraph) for g in runner.trainer._graphs.values())
+    opol, ovn = _oracle_twin(runner, oa, D, D * Ma, A)
+    acts_before = runner.buffer.actions.clone()
+    runner.rollout()                                                          # T x (collect, env.step, insert) + compute
     b = runner.buffer
-    # rollout outputs vs oracle evaluation of the same (obs, action)
+    if n_warm:
+        assert not torch.equal(b.actions, acts_before)                        # sampling stream advanced
     with torch.no_grad():
         obs_f = b.obs[:T].reshape(-1, D).cpu()
         act_f = b.actions.reshape(-1, 1).cpu()
@@ -284,17 +313,16 @@ def test_runner_iteration_vs_oracle(M):
     np.testing.assert_array_equal(b.share_obs[3, :, 0].cpu().numpy(), b.obs[3].reshape(N, -1).cpu().numpy())
     acts = b.actions.cpu().numpy()
     assert acts.min() >= 0 and acts.max() <= A - 1 and len(np.unique(acts)) > 1
-    # oracle buffer with the same contents
     ob = O.BufferRef(oa, Ma, D, D * Ma, A)
     for n in BUF_NAMES:
-        getattr(ob, n)[...] = getattr(b, n).cpu().numpy()
-    ovn = O.ValueNormRef()
+        if n != "returns":
+            getattr(ob, n)[...] = getattr(b, n).cpu().numpy()
     with torch.no_grad():
         nv, _ = opol.critic(torch.from_numpy(np.concatenate(ob.share_obs[-1])), None, None)
     ob.compute_returns(np.array(np.split(nv.numpy(), N)), ovn)
-    runner.compute()
     close(b.returns[:T], ob.returns[:T], 1e-5, 3e-6)
     oinfo = O.train_ref(oa, opol, ovn, ob)
+    last_obs = b.obs[-1].clone()
     info = runner.train()
     for k in oinfo:
         close(info[k], oinfo[k], 1e-4, 1e-6, k)
@@ -302,8 +330,8 @@ def test_runner_iteration_vs_oracle(M):
         close(vv, opol.actor.state_dict()[k].numpy(), 1e-4, 5e-6, k)
     for k, vv in runner.policy.critic.state_dict().items():
         close(vv, opol.critic.state_dict()[k].numpy(), 1e-4, 5e-6, k)
-    # after_update moved slot T to slot 0
-    np.testing.assert_array_equal(b.obs[0].cpu().numpy(), b.obs[-1].cpu().numpy())
+    close(runner.trainer.value_normalizer.state, ovn.state(), 2e-6, 1e-9)
+    np.testing.assert_array_equal(b.obs[0].cpu().numpy(), last_obs.cpu().numpy())     # after_update: slot T -> slot 0
 
 
 def test_checkpoint_roundtrip(M, tmp_path):

@@ -429,6 +429,98 @@ def test_mlp_full_size_linearity(ops):
     close(out.cpu()[idx], ref, 1e-5, 2e-6)
 
 
+@pytest.mark.parametrize("D,S,A,relu,B,with_rows", [(18, 54, 5, True, 3072, True), (18, 54, 5, False, 500, False),
+                                                    (30, 48, 9, True, 333, True), (64, 64, 18, True, 100, False),
+                                                    (18, 54, 5, True, 76800, False)])
+def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, with_rows):
+    """mappo_actor_update / mappo_critic_update (forward + in-kernel PPO loss + backward in one launch) against
+    (a) the standalone sequence mlp_forward -> ppo_loss_fwd_bwd -> mlp_backward and (b) torch autograd through
+    the oracle networks with the reference's loss expressions."""
+    torch.manual_seed(B + D)
+    rng = np.random.default_rng(B + A)
+    f = np.float32
+    a = O.default_args(use_ReLU=relu)
+    actor, critic = O.ActorRef(a, D, A), O.CriticRef(a, S)
+    _randomize(actor, 3); _randomize(critic, 4)
+    da, dc = ops.net_desc(D, A, 1, relu, True), ops.net_desc(S, 1, 1, relu, True)
+    pa, la, Pa = _flat_from_module(ops, actor, da, "act.action_out.linear")
+    pc, lc, Pc = _flat_from_module(ops, critic, dc, "v_out")
+    n_rows = B + 64 if with_rows else B
+    rows = rng.permutation(n_rows)[:B].astype(np.int32) if with_rows else np.arange(B, dtype=np.int32)
+    obs = rng.standard_normal((n_rows, D)).astype(f)
+    sobs = rng.standard_normal((n_rows, S)).astype(f)
+    avail = (rng.random((n_rows, A)) > 0.3).astype(f)
+    actions = rng.integers(0, A, n_rows).astype(f)
+    avail[np.arange(n_rows), actions.astype(int)] = 1.0
+    old_logp = (-np.abs(rng.standard_normal(n_rows)) * 0.3 - np.log(A)).astype(f)
+    adv = rng.standard_normal(n_rows).astype(f)
+    active = (rng.random(n_rows) > 0.25).astype(f)
+    ret = (rng.standard_normal(n_rows) * 3).astype(f)
+    ret[rng.random(n_rows) > 0.9] *= 20
+    with torch.no_grad():
+        v_now = critic(torch.from_numpy(sobs), None, None)[0].numpy().reshape(-1)
+    v_old = (v_now + rng.standard_normal(n_rows) * 0.25).astype(f)
+    vn = O.ValueNormRef(); vn.update(ret[:50].reshape(-1, 1)); vn.update(ret[rows].reshape(-1, 1))
+    d_rows = dev(rows, torch.int32) if with_rows else None
+    g = dict(obs=dev(obs), sobs=dev(sobs), avail=dev(avail), actions=dev(actions), old=dev(old_logp), adv=dev(adv),
+             active=dev(active), ret=dev(ret), vold=dev(v_old), vn=dev(vn.state()))
+    mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ops.minibatch_moments(g["ret"], g["active"], d_rows, B, mom)
+    cfg = ops.ppo_cfg(a)
+    ns = ops.mlp_backward_slabs(B)
+    P = ((Pa + 255) // 256) * 256 + ((Pc + 255) // 256) * 256
+    col_c = ((Pa + 255) // 256) * 256
+    # (1) fused
+    slabs = torch.zeros(ns, P, device="cuda")
+    part_a, part_c = ops.update_partials("cuda"), ops.update_partials("cuda")
+    ops.actor_update(pa, da, g["obs"], d_rows, B, g["avail"], g["actions"], g["old"], g["adv"], g["active"], mom, cfg, slabs, P, 0, part_a)
+    ops.critic_update(pc, dc, g["sobs"], d_rows, B, g["vold"], g["ret"], g["active"], g["vn"], mom, cfg, slabs, P, col_c, part_c)
+    stats_f = torch.zeros(6, dtype=torch.float64, device="cuda")
+    ops.update_stats(part_a, part_c, B, mom, cfg, stats_f)
+    grad_f = torch.zeros(P, device="cuda")
+    ops.slab_reduce(slabs, ns, P, P, grad_f)
+    # (2) unfused
+    logits, values = torch.zeros(B, A, device="cuda"), torch.zeros(B, device="cuda")
+    ops.mlp_forward(pa, da, g["obs"], d_rows, B, logits)
+    ops.mlp_forward(pc, dc, g["sobs"], d_rows, B, values)
+    dl, dv = torch.zeros(B, A, device="cuda"), torch.zeros(B, device="cuda")
+    stats_u = torch.zeros(6, dtype=torch.float64, device="cuda")
+    ops.ppo_loss_fwd_bwd(logits, values, d_rows, g["avail"], g["actions"], g["old"], g["adv"], g["active"], g["vold"], g["ret"],
+                         g["vn"], mom, dl, dv, stats_u, cfg)
+    slabs_u = torch.zeros(ns, P, device="cuda")
+    ops.mlp_backward(pa, da, g["obs"], d_rows, B, dl, slabs_u, P, 0)
+    ops.mlp_backward(pc, dc, g["sobs"], d_rows, B, dv.view(B, 1), slabs_u, P, col_c)
+    grad_u = torch.zeros(P, device="cuda")
+    ops.slab_reduce(slabs_u, ns, P, P, grad_u)
+    close(stats_f, stats_u, 1e-6, 1e-9, "stats fused vs unfused")
+    close_rel_max(grad_f[:Pa], grad_u[:Pa].cpu().numpy(), 2e-5, "actor grad fused vs unfused")
+    close_rel_max(grad_f[col_c:col_c + Pc], grad_u[col_c:col_c + Pc].cpu().numpy(), 2e-5, "critic grad fused vs unfused")
+    # (3) autograd through the oracle
+    if B <= 4000:
+        t = lambda x: torch.from_numpy(x)
+        r_ = rows.astype(np.int64)
+        lp, ent, _ = actor.evaluate_actions(t(obs[r_]), None, t(actions[r_]).view(-1, 1), None, t(avail[r_]), t(active[r_]).view(-1, 1))
+        vals = critic(t(sobs[r_]), None, None)[0]
+        act_t, adv_t, old_t = t(active[r_]).view(-1, 1), t(adv[r_]).view(-1, 1), t(old_logp[r_]).view(-1, 1)
+        imp = torch.exp(lp - old_t)
+        surr = torch.min(imp * adv_t, torch.clamp(imp, 1 - a.clip_param, 1 + a.clip_param) * adv_t)
+        pl = (-surr * act_t).sum() / act_t.sum()
+        (pl - a.entropy_coef * ent).backward()
+        tgt = vn.normalize(t(ret[r_]).view(-1, 1))
+        vo = t(v_old[r_]).view(-1, 1)
+        vclip = vo + (vals - vo).clamp(-a.clip_param, a.clip_param)
+        l = torch.max(O.huber_ref(tgt - vals, a.huber_delta), O.huber_ref(tgt - vclip, a.huber_delta))
+        vl = (l * act_t).sum() / act_t.sum()
+        (vl * a.value_loss_coef).backward()
+        s = stats_f.cpu().numpy()
+        close([s[0], s[1], s[2], s[3]], [vl.item(), pl.item(), ent.item(), imp.mean().item()], 1e-5, 1e-7, "stats vs autograd")
+        gf = grad_f.cpu().numpy()
+        for key, off, shape in la:
+            close_rel_max(gf[off: off + int(np.prod(shape))].reshape(shape), dict(actor.named_parameters())[key].grad.numpy(), 1e-4, f"actor {key}")
+        for key, off, shape in lc:
+            close_rel_max(gf[col_c + off: col_c + off + int(np.prod(shape))].reshape(shape), dict(critic.named_parameters())[key].grad.numpy(), 1e-4, f"critic {key}")
+
+
 # ------------------------------------------------------------------------------------------------------
 def test_clip_adam_vs_oracle_and_torch(ops):
     rng = np.random.default_rng(2)
