@@ -95,6 +95,7 @@ class R_MAPPOPolicy:
 
         self.actor = R_Actor(args, self.obs_space, self.act_space, self.device, flat=self.flat_params[:pa_pad])
         self.critic = R_Critic(args, self.share_obs_space, self.device, flat=self.flat_params[pa_pad:])
+        self._side_stream = None
         self.actor_optimizer = FlatAdam(self, 0, self.lr, self.opti_eps, self.weight_decay)
         self.critic_optimizer = FlatAdam(self, 1, self.critic_lr, self.opti_eps, self.weight_decay)
 
@@ -138,9 +139,18 @@ class R_MAPPOPolicy:
         avail = buffer.available_actions[step].view(R, -1) if use_available_actions else None
         out = (buffer.actions[step].view(R), buffer.action_log_probs[step].view(R))
         masks = buffer.masks[step].view(R, 1)
+        # the two networks are independent: the critic runs on a side stream next to the actor (also inside a
+        # captured hipGraph, where the fork/join becomes two parallel branches)
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        side = self._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _, rnn_c = self.critic(buffer.share_obs[step].view(R, -1),
+                                   buffer.rnn_states_critic[step].view(R, buffer.recurrent_N, -1), masks,
+                                   out=buffer.value_preds[step].view(R, 1))
         _, _, rnn_a = self.actor(buffer.obs[step].view(R, -1), buffer.rnn_states[step].view(R, buffer.recurrent_N, -1),
                                  masks, avail, deterministic, out=out, counter=step)
-        _, rnn_c = self.critic(buffer.share_obs[step].view(R, -1),
-                               buffer.rnn_states_critic[step].view(R, buffer.recurrent_N, -1), masks,
-                               out=buffer.value_preds[step].view(R, 1))
+        cur.wait_stream(side)
         return buffer.actions[step], rnn_a, rnn_c

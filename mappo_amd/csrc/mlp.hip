@@ -124,6 +124,12 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, WAVE); }
 
+// fire-and-forget LDS float add (ds_add_f32): used where exactly one wave adds into a location per phase, so the
+// result does not depend on arrival order
+__device__ __forceinline__ void lds_add(float *p, float v) {
+  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // row (feature within a 32-row MFMA tile) held by accumulator register `reg` of lane-half `half`
 #define ROWMAP(reg, half) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (half))
 
@@ -139,8 +145,9 @@ __device__ __forceinline__ float4 vec4_of(const float *sV, int t, int q, int hal
   return *reinterpret_cast<const float4 *>(sV + 32 * t + 8 * q + 4 * half);
 }
 
-// Workgroup-cooperative staging: global W[f][k] (row-major, K columns) -> LDS dst[k*stride + f], rows k in
-// [K, Kpad) zeroed.  All global loads of a thread are issued before its LDS writes (16-byte loads when aligned).
+// Workgroup-cooperative staging of one weight matrix: global W[f][k] (row-major, K columns) -> LDS dst[k*stride + f],
+// rows k in [K, Kpad) zeroed.  Loads are UNCONDITIONAL (clamped index) and all issued before the first LDS write, so a
+// thread pays one memory latency for its whole share (a predicated load is waited for individually by hipcc).
 __device__ __forceinline__ void stage_weight_T(float *dst, const float *__restrict__ src, int F, int K, int Kpad, int stride) {
   const int total = F * K;
   const int nthr = blockDim.x, tid = threadIdx.x;
@@ -149,10 +156,7 @@ __device__ __forceinline__ void stage_weight_T(float *dst, const float *__restri
     for (int i0 = 0; i0 < n4; i0 += 8 * nthr) {
       float4 v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int i = i0 + j * nthr + tid;
-        if (i < n4) v[j] = reinterpret_cast<const float4 *>(src)[i];
-      }
+      for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const float4 *>(src)[min(i0 + j * nthr + tid, n4 - 1)];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int i = i0 + j * nthr + tid;
@@ -169,9 +173,15 @@ __device__ __forceinline__ void stage_weight_T(float *dst, const float *__restri
       }
     }
   } else {
-    for (int e = tid; e < total; e += nthr) {
-      const int f = e / K, k = e - f * K;
-      dst[k * stride + f] = src[e];
+    for (int e0 = 0; e0 < total; e0 += 8 * nthr) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[min(e0 + j * nthr + tid, total - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * nthr + tid;
+        if (e < total) { const int f = e / K; dst[(e - f * K) * stride + f] = v[j]; }
+      }
     }
   }
   for (int e = tid; e < F * (Kpad - K); e += nthr) {
@@ -179,88 +189,118 @@ __device__ __forceinline__ void stage_weight_T(float *dst, const float *__restri
     dst[k * stride + f] = 0.f;
   }
 }
-__device__ __forceinline__ void stage_vec(float *dst, const float *__restrict__ src, int n, int npad, float fill) {
-  for (int e = threadIdx.x; e < npad; e += blockDim.x) dst[e] = (src != nullptr && e < n) ? src[e] : fill;
+
+// All per-feature vectors of the network in ONE pass: element e of the concatenated LDS vector area
+// [fn_w 64 | fn_b 64 | b1 ln1_w ln1_b | (b2 ln2_w ln2_b) x LN | bh 32] maps to a global offset or a fill value.
+template <int LN>
+__device__ __forceinline__ void stage_vectors(float *lds, const LdsMap &m, const float *__restrict__ params, const NetOff &o,
+                                              const mappo_net_desc &d) {
+  const int D = d.in_dim, A = d.out_dim;
+  const int n_total = 2 * MAXD + 3 * HID * (1 + LN) + 32;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  for (int e0 = 0; e0 < n_total; e0 += 4 * nthr) {
+    float v[4]; int dsti[4]; bool wr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int e = e0 + j * nthr + tid;
+      int src = -1; float fill = 0.f; int dst = m.fn_w;
+      wr[j] = e < n_total;
+      if (e < MAXD) { dst = m.fn_w + e; if (d.use_feature_norm) { if (e < D) src = o.fn_w + e; } else fill = e < D ? 1.f : 0.f; }
+      else if (e < 2 * MAXD) { const int i = e - MAXD; dst = m.fn_b + i; if (d.use_feature_norm && i < D) src = o.fn_b + i; }
+      else if (e < 2 * MAXD + 3 * HID) { const int i = e - 2 * MAXD; dst = m.b1 + i; src = o.b1 + i; }
+      else if (e < 2 * MAXD + 3 * HID * (1 + LN)) {
+        const int i = e - 2 * MAXD - 3 * HID, l = i / (3 * HID), r = i - l * 3 * HID;
+        dst = (l == 0 ? m.b2[0] : m.b2[LN > 1 ? 1 : 0]) + r;
+        src = (l == 0 ? o.b2[0] : o.b2[LN > 1 ? 1 : 0]) + r;
+      } else { const int i = e - 2 * MAXD - 3 * HID * (1 + LN); dst = m.bh + i; if (i < A) src = o.bh + i; }
+      const float ld = params[src >= 0 ? src : 0];        // unconditional load, selected below
+      v[j] = src >= 0 ? ld : fill;
+      dsti[j] = dst;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (wr[j]) lds[dsti[j]] = v[j];
+  }
 }
 
 template <int LN>
 __device__ __forceinline__ void stage_all_weights(float *lds, const LdsMap &m, const float *__restrict__ params,
                                                   const NetOff &o, const mappo_net_desc &d) {
   const int D = d.in_dim, Dp = (D + 1) & ~1, A = d.out_dim;
+  stage_vectors<LN>(lds, m, params, o, d);
   stage_weight_T(lds + m.w1, params + o.w1, HID, D, Dp, WP);
 #pragma unroll
   for (int l = 0; l < LN; ++l) stage_weight_T(lds + m.w2[l], params + o.w2[l], HID, HID, HID, WP);
   // head: dst[k*HP + a] = Wh[a][k]; columns a >= A are zero
-  for (int e = threadIdx.x; e < HID * 32; e += blockDim.x) {
-    const int a = e >> 6, k = e & 63;                       // consecutive threads read consecutive k of row a
-    lds[m.wh + k * HP + a] = (a < A) ? params[o.wh + a * HID + k] : 0.f;
-  }
-  if (d.use_feature_norm) {
-    stage_vec(lds + m.fn_w, params + o.fn_w, D, MAXD, 0.f);
-    stage_vec(lds + m.fn_b, params + o.fn_b, D, MAXD, 0.f);
-  } else {
-    for (int e = threadIdx.x; e < MAXD; e += blockDim.x) { lds[m.fn_w + e] = e < D ? 1.f : 0.f; lds[m.fn_b + e] = 0.f; }
-  }
-  stage_vec(lds + m.b1, params + o.b1, HID, HID, 0.f);
-  stage_vec(lds + m.ln1_w, params + o.ln1_w, HID, HID, 0.f);
-  stage_vec(lds + m.ln1_b, params + o.ln1_b, HID, HID, 0.f);
+  {
+    const int nthr = blockDim.x, tid = threadIdx.x, total = HID * 32, real = A * HID;
+    for (int e0 = 0; e0 < total; e0 += 8 * nthr) {
+      float v[8];
 #pragma unroll
-  for (int l = 0; l < LN; ++l) {
-    stage_vec(lds + m.b2[l], params + o.b2[l], HID, HID, 0.f);
-    stage_vec(lds + m.ln2_w[l], params + o.ln2_w[l], HID, HID, 0.f);
-    stage_vec(lds + m.ln2_b[l], params + o.ln2_b[l], HID, HID, 0.f);
+      for (int j = 0; j < 8; ++j) v[j] = params[o.wh + min(e0 + j * nthr + tid, real - 1)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int e = e0 + j * nthr + tid;
+        if (e < total) { const int a = e >> 6, k = e & 63; lds[m.wh + k * HP + a] = (e < real) ? v[j] : 0.f; }
+      }
+    }
   }
-  stage_vec(lds + m.bh, params + o.bh, A, 32, 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------
-// input rows: register prefetch (global -> VGPR for the NEXT tile) and LDS commit (VGPR -> tX[k][s])
+// input rows.  Lane (s = lane & 31, half = lane >> 5) fetches features k = 2j + half of sample s of the NEXT tile
+// into registers (NV = ceil(D/2) <= 16 | 32); at the top of the tile the LayerNorm over the D input features
+// (mlp.py:45,51-52) is a per-lane register loop plus one cross-half exchange, and xhat0 goes to tX[k][s] in the
+// layout the B operand of layer 1 reads.  (A wave load touches 32 rows, one word each; the rows of a tile are
+// re-touched by the next j while still in L1.)
 // ------------------------------------------------------------------------------------------------
-// WIDE = false (in_dim <= 32): a wave-instruction fetches two samples (lanes 0-31 / 32-63), 16 registers;
-// WIDE = true  (in_dim <= 64): one sample per wave-instruction, 32 registers.
 template <bool WIDE>
 struct RowPrefetch {
   float v[WIDE ? TS : TS / 2];
-  int my_row;         // lane s < 32: source row of sample s of the prefetched tile
+  int my_row;         // source row of sample lane&31 of the prefetched tile (both halves hold it)
   int n_valid;
 };
 
 template <bool WIDE>
 __device__ __forceinline__ void prefetch_rows(RowPrefetch<WIDE> &pf, const float *__restrict__ x,
                                               const int32_t *__restrict__ rows, int64_t base, int64_t B, int D, int lane) {
+  const int s = lane & 31, half = lane >> 5;
   pf.n_valid = (int)max((int64_t)0, min((int64_t)TS, B - base));
   pf.my_row = 0;
-  if (lane < pf.n_valid) pf.my_row = rows ? rows[base + lane] : (int)(base + lane);
-  const int kl = WIDE ? lane : (lane & 31), sub = WIDE ? 0 : (lane >> 5);
-  constexpr int NV = WIDE ? TS : TS / 2, STEP = WIDE ? 1 : 2;
+  const bool ok = s < pf.n_valid;
+  if (ok) pf.my_row = rows ? rows[base + s] : (int)(base + s);
+  const float *src = x + (int64_t)pf.my_row * D + half;
+  constexpr int NV = WIDE ? TS : TS / 2;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
-    const int s = j * STEP + sub;
-    const int row = __shfl(pf.my_row, s, WAVE);
     pf.v[j] = 0.f;
-    if (kl < D && s < pf.n_valid) pf.v[j] = x[(int64_t)row * D + kl];
+    if (ok && 2 * j + half < D) pf.v[j] = src[2 * j];
   }
 }
 
+// tX[k][s] <- xhat0 (feature LayerNorm, affine applied on read) or the raw input when feature norm is off
 template <bool WIDE>
-__device__ __forceinline__ void commit_rows(float *tX, const RowPrefetch<WIDE> &pf, int Dp, int lane) {
-  const int kl = WIDE ? lane : (lane & 31), sub = WIDE ? 0 : (lane >> 5);
-  constexpr int NV = WIDE ? TS : TS / 2, STEP = WIDE ? 1 : 2;
+__device__ __forceinline__ void commit_rows(float *tX, const RowPrefetch<WIDE> &pf, int D, int Dp, int lane, bool feature_norm) {
+  const int s = lane & 31, half = lane >> 5;
+  constexpr int NV = WIDE ? TS : TS / 2;
+  float mean = 0.f, rstd = 1.f;
+  if (feature_norm) {
+    float sum = 0.f;
 #pragma unroll
-  for (int j = 0; j < NV; ++j)
-    if (kl < Dp) tX[kl * TP + j * STEP + sub] = pf.v[j];
-}
-
-// LayerNorm over the D input features of each sample, in place: tX <- xhat0 (the affine is applied on read).
-__device__ __forceinline__ void feature_norm_tile(float *tX, int D, int l31, int half, bool enabled) {
-  if (!enabled) return;
-  float s = 0.f;
-  for (int k = half; k < D; k += 2) s += tX[k * TP + l31];
-  const float mean = xhalf_sum(s) / (float)D;
-  float q = 0.f;
-  for (int k = half; k < D; k += 2) { const float c = tX[k * TP + l31] - mean; q += c * c; }
-  const float rstd = 1.0f / sqrtf(xhalf_sum(q) / (float)D + LN_EPS);
-  for (int k = half; k < D; k += 2) tX[k * TP + l31] = (tX[k * TP + l31] - mean) * rstd;
+    for (int j = 0; j < NV; ++j) sum += pf.v[j];                 // slots beyond D hold 0
+    mean = xhalf_sum(sum) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const float c = (2 * j + half < D) ? pf.v[j] - mean : 0.f;
+      q += c * c;
+    }
+    rstd = 1.0f / sqrtf(xhalf_sum(q) / (float)D + LN_EPS);
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int k = 2 * j + half;
+    if (k < Dp) tX[k * TP + s] = (k < D) ? (pf.v[j] - mean) * rstd : 0.f;
+  }
 }
 
 // acc (2 tiles of 32 features) <- bias
@@ -303,21 +343,14 @@ __device__ __forceinline__ void xhat_to_tile(float *tile, const f32x16 (&a)[2], 
 // step kk+1 are fetched from LDS before the MFMAs of step kk issue
 __device__ __forceinline__ void layer_mfma(f32x16 (&acc)[2], const float *sW, const float *tin, const float *sG,
                                            const float *sBt, int ksteps, int l31, int half) {
-  int k = half;
-  float b = tin[k * TP + l31] * sG[k] + sBt[k];
-  float a0 = sW[k * WP + l31], a1 = sW[k * WP + 32 + l31];
-#pragma unroll 2
+  // unrolled so that hipcc issues the LDS reads of several k-steps ahead of the MFMA chain that consumes them
+#pragma unroll 8
   for (int kk = 0; kk < ksteps; ++kk) {
-    float nb = 0.f, na0 = 0.f, na1 = 0.f;
-    if (kk + 1 < ksteps) {
-      k += 2;
-      nb = tin[k * TP + l31] * sG[k] + sBt[k];
-      na0 = sW[k * WP + l31];
-      na1 = sW[k * WP + 32 + l31];
-    }
+    const int k = 2 * kk + half;
+    const float b = tin[k * TP + l31] * sG[k] + sBt[k];
+    const float a0 = sW[k * WP + l31], a1 = sW[k * WP + 32 + l31];
     acc[0] = mfma(a0, b, acc[0]);
     acc[1] = mfma(a1, b, acc[1]);
-    b = nb; a0 = na0; a1 = na1;
   }
 }
 
@@ -375,18 +408,10 @@ __device__ __forceinline__ f32x16 head_forward(const float *lds, const LdsMap &m
     acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
   }
   const float *sW = lds + m.wh;
-  int k = half;
-  float a = sW[k * HP + l31], b = tLast[k * TP + l31] * sG[k] + sBt[k];
-#pragma unroll 2
+#pragma unroll 16
   for (int kk = 0; kk < HID / 2; ++kk) {
-    float na = 0.f, nb = 0.f;
-    if (kk + 1 < HID / 2) {
-      k += 2;
-      na = sW[k * HP + l31];
-      nb = tLast[k * TP + l31] * sG[k] + sBt[k];
-    }
-    acc = mfma(a, b, acc);
-    a = na; b = nb;
+    const int k = 2 * kk + half;
+    acc = mfma(sW[k * HP + l31], tLast[k * TP + l31] * sG[k] + sBt[k], acc);
   }
   return acc;
 }
@@ -454,11 +479,9 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
   for (; tile < n_tiles; tile += tile_stride) {
     const int64_t base = tile * TS;
     const int n_valid = pf.n_valid;
-    commit_rows(tX, pf, Dp, lane);
+    commit_rows(tX, pf, D, Dp, lane, p.desc.use_feature_norm != 0);
     wave_lds_sync();
     prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);
-    feature_norm_tile(tX, D, l31, half, p.desc.use_feature_norm != 0);
-    wave_lds_sync();
     TileStats<LN> st;
     tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
     const f32x16 z = head_forward(lds, m, tH + LN * HID * TP, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN), l31, half);
@@ -506,6 +529,36 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
     wave_lds_sync();
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// diagnostic build only (-DMLP_STAMPS, scripts/stamps.py): per-phase cycle shares of the update kernel.
+// In the product build STAMP() expands to nothing and no stamp executes.
+// ------------------------------------------------------------------------------------------------
+#ifdef MLP_STAMPS
+#define N_STAMPS 16
+__device__ unsigned long long *g_stamp_buf = nullptr;      // [gridDim.x][N_STAMPS], set by mappo_debug_set_stamps
+#define STAMP_DECL unsigned long long st_acc_[N_STAMPS] = {}; unsigned long long st_prev_ = __builtin_readcyclecounter();
+#define STAMP(i)                                                          \
+  do {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+    const unsigned long long now_ = __builtin_readcyclecounter();         \
+    st_acc_[i] += now_ - st_prev_;                                        \
+    st_prev_ = now_;                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                    \
+  } while (0)
+#define STAMP_FLUSH()                                                                     \
+  do {                                                                                    \
+    if (g_stamp_buf && threadIdx.x == 0)                                                  \
+      for (int i_ = 0; i_ < N_STAMPS; ++i_) g_stamp_buf[blockIdx.x * N_STAMPS + i_] = st_acc_[i_]; \
+  } while (0)
+extern "C" int mappo_debug_set_stamps(unsigned long long *buf) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &buf, sizeof(buf)) == hipSuccess ? 0 : -2;
+}
+#else
+#define STAMP_DECL
+#define STAMP(i) do { } while (0)
+#define STAMP_FLUSH() do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // update kernel: forward + head gradient (external | PPO actor loss | value loss) + backward
@@ -612,7 +665,7 @@ template <int HEAD, bool WIDE>
 __device__ __forceinline__ void prefetch_loss(LossPrefetch &lp, const UpdArgs &p, const RowPrefetch<WIDE> &pf, int lane, int A) {
   lp.f0 = lp.f1 = lp.f2 = lp.f3 = 0.f;
   lp.dead = 0u;
-  if (HEAD == 0 || lane >= pf.n_valid) return;
+  if (HEAD == 0 || lane >= pf.n_valid) return;        // lanes 0..31 carry the per-sample loss inputs
   const int64_t row = pf.my_row;
   if (HEAD == 1) {
     lp.f0 = p.actions[row]; lp.f1 = p.old_logp[row]; lp.f2 = p.adv[row]; lp.f3 = p.active[row];
@@ -640,10 +693,12 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   int64_t tile = (int64_t)blockIdx.x * n_waves + wave;
   RowPrefetch<WIDE> pf;
   LossPrefetch lp;
+  STAMP_DECL
   prefetch_rows(pf, p.x, p.rows, tile * TS, p.B, D, lane);
   prefetch_loss<HEAD, WIDE>(lp, p, pf, lane, A);
   stage_all_weights<LN>(lds, m, p.params, o, p.desc);
   __syncthreads();
+  STAMP(0);   // staging
   float *tX = lds + m.tiles + wave * m.wave_stride;
   float *tH = tX + m.x_rows * TP;
   float *tZ = tH + (LN + 1) * HID * TP;
@@ -684,15 +739,15 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     const int64_t base = tile * TS;
     const int n_valid = pf.n_valid;
     const LossPrefetch cur = lp;
-    commit_rows(tX, pf, Dp, lane);
+    commit_rows(tX, pf, D, Dp, lane, p.desc.use_feature_norm != 0);
     wave_lds_sync();
     prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);   // next tile, hidden under the MFMAs below
     prefetch_loss<HEAD, WIDE>(lp, p, pf, lane, A);
-    feature_norm_tile(tX, D, l31, half, p.desc.use_feature_norm != 0);
-    wave_lds_sync();
+    STAMP(1);   // commit (+ feature norm) + prefetch issue
     TileStats<LN> st;
     tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
     float *tLast = tH + LN * HID * TP;
+    STAMP(2);   // trunk forward
 
     // ---- head gradient into tZ[s][a] ----
     if (HEAD == 0) {
@@ -717,19 +772,26 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
               if (cur.dead & (1u << a)) { za = -1e10f; zl[a] = za; }
               zmax = fmaxf(zmax, za);
             }
+            // e_a = exp(z_a - max) is computed once and parked behind the logits (columns 16..31 of the 33-wide row)
+            const bool park = A <= 16;
             float se = 0.f;
-            for (int a = 0; a < A; ++a) se += expf(zl[a] - zmax);
-            const float lse = zmax + logf(se);
+            for (int a = 0; a < A; ++a) { const float e = expf(zl[a] - zmax); if (park) zl[16 + a] = e; se += e; }
+            const float log_se = logf(se), inv_se = 1.0f / se;
             float Hent = 0.f;
-            for (int a = 0; a < A; ++a) { const float l_ = zl[a] - lse; Hent -= expf(l_) * fmaxf(l_, -FLT_MAX); }
-            const float logp = zl[act] - lse;
+            for (int a = 0; a < A; ++a) {
+              const float l_ = (zl[a] - zmax) - log_se;
+              const float pa = (park ? zl[16 + a] : expf(zl[a] - zmax)) * inv_se;
+              Hent -= pa * fmaxf(l_, -FLT_MAX);
+            }
+            const float logp = (zl[act] - zmax) - log_se;
             const float ratio = expf(logp - old_lp);
             const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * adv;
             const float w_pi = p.cfg.use_policy_active_masks ? active : 1.f;
             const float dlogp = (s1 <= s2) ? -(w_pi * scale_pi) * adv * ratio : 0.f;
             const float ce = p.cfg.entropy_coef * w_pi * scale_pi;
             for (int a = 0; a < A; ++a) {
-              const float l_ = zl[a] - lse, pa = expf(l_);
+              const float l_ = (zl[a] - zmax) - log_se;
+              const float pa = (park ? zl[16 + a] : expf(zl[a] - zmax)) * inv_se;
               float g = dlogp * ((a == act ? 1.f : 0.f) - pa) + ce * pa * (l_ + Hent);
               if (cur.dead & (1u << a)) g = 0.f;
               zl[a] = g;
@@ -779,6 +841,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
       }
     }
     wave_lds_sync();
+    STAMP(3);   // head forward + loss
 
     // ---- (A) head weight / bias gradients:  dWh[a][f] += sum_s dz[s][a] * h_last[f][s] ----
     {
@@ -810,6 +873,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         dH[1] = mfma(sW[(32 + l31) * HP + a], b, dH[1]);
       }
     }
+    STAMP(4);   // head grads (A), (B)
     // ---- hidden layers, last to first ----
 #pragma unroll
     for (int l = LN; l >= 1; --l) {
@@ -817,6 +881,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
       float *tPrev = tH + (l - 1) * HID * TP;   // xhat of the layer's input
       ln_act_backward<RELU>(dH, tCur, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW[l], gLnB[l], lane, l31, half);
       gB[l] += tile_row_sum(tCur, lane);
+      STAMP(5);   // LN + act backward (hidden)
       // dW2[f_out][k_in] += sum_s dz[f_out][s] * h_prev[k_in][s]
       {
         const float *sG = lds + ln_w_of<LN>(m, l - 1), *sBt = lds + ln_b_of<LN>(m, l - 1);
@@ -832,6 +897,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
           gW2[l - 1][1][1] = mfma(a1, b1, gW2[l - 1][1][1]);
         }
       }
+      STAMP(6);   // dW2
       // d h_prev = W2^T . dz
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -848,12 +914,14 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         }
       }
       wave_lds_sync();
+      STAMP(7);   // dH (hidden)
     }
     // ---- layer 1 ----
     {
       float *tCur = tH;
       ln_act_backward<RELU>(dH, tCur, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW[0], gLnB[0], lane, l31, half);
       gB[0] += tile_row_sum(tCur, lane);
+      STAMP(8);   // LN + act backward (layer 1)
       // dW1[f_out][k] += sum_s dz1[f_out][s] * xn[k][s],  xn = xhat0 * gamma0 + beta0
       {
         const int k0 = l31, k1 = 32 + l31;
@@ -874,6 +942,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
           }
         }
       }
+      STAMP(9);   // dW1
       // feature-norm gradients: dxn = W1^T . dz1 ; dgamma0[k] = sum_s dxn*xhat0 ; dbeta0[k] = sum_s dxn
       if (p.desc.use_feature_norm) {
         f32x16 dX[2];
@@ -910,8 +979,10 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         }
       }
       wave_lds_sync();
+      STAMP(10);  // dX + feature-norm grads
     }
   }
+  STAMP(11);    // (loop exit)
 
   // ---- loss statistics of this workgroup ----
   if (HEAD != 0) {
@@ -931,35 +1002,55 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     if (wave / n_reg == round) {
       float *red = red0 + (wave % n_reg) * P;
       const bool first = (round == 0);
-#define RED(idx, val) do { const int i_ = (idx); if (first) red[i_] = (val); else red[i_] += (val); } while (0)
+      // one accumulator tile: 16 old values are read, then 16 sums written (reads never wait on the writes)
+      auto red_tile = [&](const f32x16 &acc, int idx0, int ld, bool valid) {
+        if (!valid) return;
+        float old[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) old[r] = first ? 0.f : red[idx0 + ((r & 3) + 8 * (r >> 2)) * ld];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[idx0 + ((r & 3) + 8 * (r >> 2)) * ld] = old[r] + acc[r];
+      };
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = 32 * ti + ROWMAP(r, half);
+        for (int tj = 0; tj < 2; ++tj) {
+          const int col = 32 * tj + l31, row0 = 32 * ti + 4 * half;
+          red_tile(gW1[ti][tj], o.w1 + row0 * D + col, D, col < D);
 #pragma unroll
-          for (int tj = 0; tj < 2; ++tj) {
-            const int col = 32 * tj + l31;
-            if (col < D) RED(o.w1 + row * D + col, gW1[ti][tj][r]);
-#pragma unroll
-            for (int l = 0; l < LN; ++l) RED(o.w2[l] + row * HID + col, gW2[l][ti][tj][r]);
-          }
+          for (int l = 0; l < LN; ++l) red_tile(gW2[l][ti][tj], o.w2[l] + row0 * HID + col, HID, true);
         }
+      // head: rows a = ROWMAP(r, half) < A only
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj)
+      for (int tj = 0; tj < 2; ++tj) {
+        float old[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int a = ROWMAP(r, half);
-          if (a < A) RED(o.wh + a * HID + 32 * tj + l31, gWh[tj][r]);
-        }
-      RED(o.b1 + lane, gB[0]); RED(o.ln1_w + lane, gLnW[0]); RED(o.ln1_b + lane, gLnB[0]);
+        for (int r = 0; r < 16; ++r) { const int a = ROWMAP(r, half); old[r] = (!first && a < A) ? red[o.wh + a * HID + 32 * tj + l31] : 0.f; }
 #pragma unroll
-      for (int l = 0; l < LN; ++l) {
-        RED(o.b2[l] + lane, gB[l + 1]); RED(o.ln2_w[l] + lane, gLnW[l + 1]); RED(o.ln2_b[l] + lane, gLnB[l + 1]);
+        for (int r = 0; r < 16; ++r) { const int a = ROWMAP(r, half); if (a < A) red[o.wh + a * HID + 32 * tj + l31] = old[r] + gWh[tj][r]; }
       }
-      if (half == 0 && l31 < A) RED(o.bh + l31, gBh);
-      if (p.desc.use_feature_norm && lane < D) { RED(o.fn_w + lane, gFnW); RED(o.fn_b + lane, gFnB); }
-#undef RED
+      {
+        float vals[3 * (LN + 1) + 3]; int idx[3 * (LN + 1) + 3]; bool ok[3 * (LN + 1) + 3];
+        int n = 0;
+        vals[n] = gB[0]; idx[n] = o.b1 + lane; ok[n++] = true;
+        vals[n] = gLnW[0]; idx[n] = o.ln1_w + lane; ok[n++] = true;
+        vals[n] = gLnB[0]; idx[n] = o.ln1_b + lane; ok[n++] = true;
+#pragma unroll
+        for (int l = 0; l < LN; ++l) {
+          vals[n] = gB[l + 1]; idx[n] = o.b2[l] + lane; ok[n++] = true;
+          vals[n] = gLnW[l + 1]; idx[n] = o.ln2_w[l] + lane; ok[n++] = true;
+          vals[n] = gLnB[l + 1]; idx[n] = o.ln2_b[l] + lane; ok[n++] = true;
+        }
+        vals[n] = gBh; idx[n] = o.bh + l31; ok[n++] = (half == 0 && l31 < A);
+        const bool fn = p.desc.use_feature_norm && lane < D;
+        vals[n] = gFnW; idx[n] = o.fn_w + lane; ok[n++] = fn;
+        vals[n] = gFnB; idx[n] = o.fn_b + lane; ok[n++] = fn;
+        float old[3 * (LN + 1) + 3];
+#pragma unroll
+        for (int i = 0; i < 3 * (LN + 1) + 3; ++i) old[i] = (!first && ok[i]) ? red[idx[i]] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 3 * (LN + 1) + 3; ++i) if (ok[i]) red[idx[i]] = old[i] + vals[i];
+      }
     }
     __syncthreads();
   }
@@ -969,6 +1060,8 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   } else {
     for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red0[e];
   }
+  STAMP(12);    // block reduction + slab write
+  STAMP_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -24,21 +24,24 @@ __device__ __forceinline__ int seg_of(const SegBounds &sb, int64_t i) {
   return s;
 }
 
-// grad[p] = sum over slabs (per-workgroup partial gradients written by mappo_mlp_backward); coalesced in p.
-__global__ __launch_bounds__(OPT_BLOCK) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs,
-                                                               int64_t stride, int64_t P, float *__restrict__ grad) {
-  const int64_t p = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x;
+// grad[p] = sum over slabs (per-workgroup partial gradients written by the update kernels); coalesced in p,
+// 16 independent loads in flight per thread (the pass is a pure HBM/L2 stream: n_slabs * P * 4 bytes).
+#define SLAB_BLOCK 128
+__global__ __launch_bounds__(SLAB_BLOCK) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs,
+                                                                int64_t stride, int64_t P, float *__restrict__ grad) {
+  const int64_t p = (int64_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
   if (p >= P) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
   int s = 0;
-  for (; s + 4 <= n_slabs; s += 4) {
-    s0 += slabs[(size_t)(s + 0) * stride + p];
-    s1 += slabs[(size_t)(s + 1) * stride + p];
-    s2 += slabs[(size_t)(s + 2) * stride + p];
-    s3 += slabs[(size_t)(s + 3) * stride + p];
+  for (; s + 16 <= n_slabs; s += 16) {
+    float v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = slabs[(size_t)(s + j) * stride + p];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j & 3] += v[j];          // fixed association: deterministic
   }
-  for (; s < n_slabs; ++s) s0 += slabs[(size_t)s * stride + p];
-  grad[p] = (s0 + s1) + (s2 + s3);
+  for (; s < n_slabs; ++s) acc[0] += slabs[(size_t)s * stride + p];
+  grad[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 __global__ __launch_bounds__(OPT_BLOCK) void sqnorm_partial_kernel(const float *__restrict__ grad, int64_t P,
@@ -111,8 +114,8 @@ extern "C" int64_t mappo_optim_workspace_bytes(int64_t P) {
 extern "C" int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t slab_stride, int64_t P, float *grad,
                                  mappo_stream_t stream) {
   MAPPO_REQUIRE(slabs && grad && n_slabs > 0 && P > 0 && slab_stride >= P, "slab_reduce: bad arguments");
-  const int nblk = (int)((P + OPT_BLOCK - 1) / OPT_BLOCK);
-  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, as_stream(stream), slabs,
+  const int nblk = (int)((P + SLAB_BLOCK - 1) / SLAB_BLOCK);
+  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_kernel, dim3(nblk), dim3(SLAB_BLOCK), 0, as_stream(stream), slabs,
               (int)n_slabs, slab_stride, P, grad);
   MAPPO_CHECK_LAUNCH("slab_reduce");
   return MAPPO_OK;

@@ -80,18 +80,24 @@ __global__ __launch_bounds__(PL_BLOCK) void ppo_loss_kernel(PlArgs p) {
         if (av && av[a] == 0.f) { za = -1e10f; dead |= (1u << a); z[a] = za; }
         zmax = fmaxf(zmax, za);
       }
-      // ---- pass 2: log-sum-exp ----
+      // ---- pass 2: e_a = exp(z_a - max), kept in registers when A <= 8 (one exp per action instead of three) ----
+      float ereg[8];
+      const bool small = A <= 8;
       float se = 0.f;
-      for (int a = 0; a < A; ++a) se += expf(z[a] - zmax);
-      const float lse = zmax + logf(se);
+#pragma unroll
+      for (int a = 0; a < 8; ++a) { ereg[a] = 0.f; if (small && a < A) { ereg[a] = expf(z[a] - zmax); se += ereg[a]; } }
+      if (!small) for (int a = 0; a < A; ++a) se += expf(z[a] - zmax);
+      const float log_se = logf(se), inv_se = 1.0f / se;
       // ---- pass 3: entropy  H = -sum p * max(logp, finfo.min) ----
       float H = 0.f;
-      for (int a = 0; a < A; ++a) {
-        const float lp = z[a] - lse;
-        H -= expf(lp) * fmaxf(lp, -FLT_MAX);
+      if (small) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) if (a < A) { const float lp = (z[a] - zmax) - log_se; H -= ereg[a] * inv_se * fmaxf(lp, -FLT_MAX); }
+      } else {
+        for (int a = 0; a < A; ++a) { const float lp = (z[a] - zmax) - log_se; H -= expf(lp) * fmaxf(lp, -FLT_MAX); }
       }
       // ---- policy surrogate (r_mappo.py:124-134) ----
-      const float logp = z[act] - lse;
+      const float logp = (z[act] - zmax) - log_se;
       const float ratio = expf(logp - old_lp);
       const float s1 = ratio * adv;
       const float s2 = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * adv;
@@ -99,12 +105,21 @@ __global__ __launch_bounds__(PL_BLOCK) void ppo_loss_kernel(PlArgs p) {
       const float dlogp = (s1 <= s2) ? -(w_pi * scale_pi) * adv * ratio : 0.f;
       const float ce = p.cfg.entropy_coef * w_pi * scale_pi;
       // ---- pass 4: d(objective)/d logits, written back into the tile ----
-      for (int a = 0; a < A; ++a) {
-        const float lp = z[a] - lse;
-        const float pa = expf(lp);
-        float g = dlogp * ((a == act ? 1.f : 0.f) - pa) + ce * pa * (lp + H);
-        if (dead & (1u << a)) g = 0.f;          // overwritten logits get no gradient
-        z[a] = g;
+      if (small) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a) if (a < A) {
+          const float lp = (z[a] - zmax) - log_se, pa = ereg[a] * inv_se;
+          float g = dlogp * ((a == act ? 1.f : 0.f) - pa) + ce * pa * (lp + H);
+          if (dead & (1u << a)) g = 0.f;
+          z[a] = g;
+        }
+      } else {
+        for (int a = 0; a < A; ++a) {
+          const float lp = (z[a] - zmax) - log_se, pa = expf(lp);
+          float g = dlogp * ((a == act ? 1.f : 0.f) - pa) + ce * pa * (lp + H);
+          if (dead & (1u << a)) g = 0.f;          // overwritten logits get no gradient
+          z[a] = g;
+        }
       }
       // ---- value loss (r_mappo.py:62-87) ----
       const float tgt = p.cfg.use_valuenorm ? (ret - vn.mean) / vn.sd : ret;

@@ -14,9 +14,10 @@ static inline int stat_blocks(int64_t n) {
   return (int)b;
 }
 
+// out[0..NV) = sum of the per-block partials; out[NV] = `extra` when extra >= 0 (the minibatch size B)
 template <int NV>
 __global__ __launch_bounds__(STAT_BLOCK) void final_reduce_kernel(const double *__restrict__ partials, int nblk,
-                                                                 double *__restrict__ out) {
+                                                                 double *__restrict__ out, double extra) {
   __shared__ double smem[16 * NV];
   double v[NV];
 #pragma unroll
@@ -29,6 +30,7 @@ __global__ __launch_bounds__(STAT_BLOCK) void final_reduce_kernel(const double *
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) out[i] = v[i];
+    if (extra >= 0.0) out[NV] = extra;
   }
 }
 
@@ -84,7 +86,7 @@ extern "C" int mappo_adv_moments(const float *returns, const float *value_preds,
   hipLaunchKernelGGL(adv_moments_kernel, dim3(nblk), dim3(STAT_BLOCK), 0, as_stream(stream), returns, value_preds,
                      active_masks, vn_state, adv, (double *)workspace, n);
   hipLaunchKernelGGL(final_reduce_kernel<3>, dim3(1), dim3(STAT_BLOCK), 0, as_stream(stream),
-                     (const double *)workspace, nblk, moments);
+                     (const double *)workspace, nblk, moments, -1.0);
   MAPPO_CHECK_LAUNCH("adv_moments");
   return MAPPO_OK;
 }
@@ -120,8 +122,6 @@ __global__ __launch_bounds__(STAT_BLOCK) void minibatch_moments_kernel(const flo
   }
 }
 
-__global__ void moments_set_count_kernel(double *mb_moments, double B) { mb_moments[3] = B; }
-
 extern "C" int64_t mappo_moments_workspace_bytes(int64_t B) { return (int64_t)STAT_MAX_BLOCKS * 3 * sizeof(double); }
 
 extern "C" int mappo_minibatch_moments(const float *returns, const float *active_masks, const int32_t *rows, int64_t B,
@@ -131,8 +131,7 @@ extern "C" int mappo_minibatch_moments(const float *returns, const float *active
   hipLaunchKernelGGL(minibatch_moments_kernel, dim3(nblk), dim3(STAT_BLOCK), 0, as_stream(stream), returns,
                      active_masks, rows, B, (double *)workspace);
   hipLaunchKernelGGL(final_reduce_kernel<3>, dim3(1), dim3(STAT_BLOCK), 0, as_stream(stream),
-                     (const double *)workspace, nblk, mb_moments);
-  hipLaunchKernelGGL(moments_set_count_kernel, dim3(1), dim3(1), 0, as_stream(stream), mb_moments, (double)B);
+                     (const double *)workspace, nblk, mb_moments, (double)B);
   MAPPO_CHECK_LAUNCH("minibatch_moments");
   return MAPPO_OK;
 }

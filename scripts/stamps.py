@@ -1,0 +1,43 @@
+"""Diagnostic (GPU box): per-phase cycle shares of mlp_update_kernel from a -DMLP_STAMPS build of mlp.hip.
+Builds gpurun_out/libmappo_hip_stamps.so, loads it INSTEAD of the product library, runs actor/critic updates."""
+import ctypes, os, subprocess, sys
+import torch
+sys.path.insert(0, '.')
+ROOT = os.getcwd()
+out = os.path.join(ROOT, 'gpurun_out', 'libmappo_hip_stamps.so')
+srcs = [os.path.join(ROOT, 'mappo_amd', 'csrc', f) for f in sorted(os.listdir(os.path.join(ROOT, 'mappo_amd', 'csrc'))) if f.endswith('.hip')]
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DMLP_STAMPS', '-w', '-o', out] + srcs)
+from mappo_amd import _lib
+_lib.LIB_PATH = out
+_lib.SIGNATURES['mappo_debug_set_stamps'] = (ctypes.c_int, [ctypes.c_void_p])
+from mappo_amd import ops
+lib = _lib.load()
+NAMES = ['staging', 'commit+prefetch+featnorm', 'trunk fwd', 'head fwd + loss', 'head grads A,B', 'LNbwd hidden', 'dW2', 'dH hidden',
+         'LNbwd L1', 'dW1', 'dX + fn grads', 'loop exit', 'block reduce + slab', '', '', '']
+class A_: pass
+a = A_(); a.clip_param=0.2; a.entropy_coef=0.01; a.value_loss_coef=1.0; a.huber_delta=10.0; a.use_huber_loss=True; a.use_clipped_value_loss=True; a.use_policy_active_masks=True; a.use_value_active_masks=True; a.use_valuenorm=True
+cfg = ops.ppo_cfg(a)
+B = 76800
+for name, D, A in (('actor', 18, 5), ('critic', 54, 1)):
+    desc = ops.net_desc(D, A); P = ops.net_param_count(desc)
+    params = torch.randn(P, device='cuda') * 0.1
+    x = torch.randn(B, D, device='cuda'); ns = ops.mlp_backward_slabs(B)
+    slabs = torch.zeros(ns, P, device='cuda'); part = ops.update_partials('cuda')
+    ret = torch.randn(B, device='cuda'); active = torch.ones(B, device='cuda')
+    mom = torch.zeros(4, dtype=torch.float64, device='cuda'); ops.minibatch_moments(ret, active, None, B, mom)
+    stamps = torch.zeros(ns * 16, dtype=torch.int64, device='cuda')
+    assert lib.mappo_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
+    def run():
+        if name == 'actor':
+            ops.actor_update(params, desc, x, None, B, torch.ones(B, A, device='cuda'), torch.randint(0, A, (B,), device='cuda').float(),
+                             -torch.rand(B, device='cuda') - 1, torch.randn(B, device='cuda'), active, mom, cfg, slabs, P, 0, part)
+        else:
+            ops.critic_update(params, desc, x, None, B, torch.randn(B, device='cuda'), ret, active, torch.tensor([0., 1., 1.], device='cuda'),
+                              mom, cfg, slabs, P, 0, part)
+    for _ in range(3): run()
+    torch.cuda.synchronize()
+    st = stamps.view(ns, 16).double().cpu()
+    mean = st.mean(0); tot = mean.sum()
+    print(f"--- {name} D={D} A={A} B={B}: {ns} blocks, mean cycles per block (wave 0) = {tot:.0f}")
+    for i, n in enumerate(NAMES):
+        if mean[i] > 0: print(f"  {n:28s} {mean[i]:9.0f} cyc  {100*mean[i]/tot:5.1f} %")
