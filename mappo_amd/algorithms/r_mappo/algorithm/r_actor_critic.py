@@ -112,7 +112,7 @@ class R_Actor(_NetBase):
             actions_f, logp = out
         if self._recurrent:
             from mappo_amd.recurrent import actor_step
-            rnn_states = actor_step(self, obs, self._in(rnn_states), self._in(masks), avail, deterministic, actions_f, logp)
+            rnn_states = actor_step(self, obs, self._in(rnn_states), self._in(masks), avail, deterministic, actions_f, logp, counter)
         else:
             if counter is None:
                 counter = self._sample_counter

@@ -108,7 +108,7 @@ class R_MAPPO():
                                  src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa)
             ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
                               src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc)
-            ops.update_stats(pa if update_actor else None, pc, B, self._mb_moments, self._cfg, self._stats)
+            ops.update_stats(pa if update_actor else None, n_slabs, pc, n_slabs, self._mb_moments, self._cfg, self._stats)
         else:
             # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
             logits = self._buf("logits", (B, A))

@@ -1,0 +1,749 @@
+// gru.hip — K9: the recurrent layer of R_Actor / R_Critic (onpolicy/algorithms/utils/rnn.py:7-80):
+//   h_t = GRU(x_t, h_{t-1} * mask_t)   (torch nn.GRU, 1 layer, gate order r,z,n; rnn.py:13,27,67)
+//   y_t = LayerNorm(h_t)               (rnn.py:22,79)          -> head (distributions.py:55-68 | v_out)
+// The reference's mask-segmented sequence run (rnn.py:30-77) equals multiplying h by mask_t before every step
+// (SURVEY.md §3.4), which is what these kernels do.
+//
+// Same transposed fp32-MFMA formulation as mlp.hip: a wavefront owns 32 sequences (chunks) and walks their L steps;
+// a lane holds one sequence and 32 of the 64 hidden features, so the gate nonlinearities, the state update, the
+// LayerNorm and the whole cell backward are per-lane register code.  W_ih / W_hh (2 x 192x64 fp32 = 98 KB) stay in
+// LDS for the workgroup's lifetime (k-major, row stride 193: conflict-free both for W.x and for W^T.dg).
+// All per-step scratch between the kernels is FEATURE-MAJOR ([feature][row], row = t*Nc + c), so accumulator-layout
+// registers are loaded/stored as coalesced 128-B segments and MFMA B operands can be read straight from HBM/L2.
+//
+//   gru_fwd_kernel   x_T[64][B], h0 -> h_t for t < L; optional per-step head output / action sampling (rollout,
+//                    get_values, evaluate) ; in training mode stores hm, r, z, n, gh_n, h' per step
+//   gru_bwd_kernel   reverse time: LayerNorm + head + in-kernel PPO loss (actor | critic) at step t, cell backward,
+//                    dx_t = W_ih^T dgi, carry = (W_hh^T dgh + dh*z) * mask ; writes dx_T, dgi_T, dghn_T,
+//                    head / rnn.norm gradient slabs and loss partial sums
+//   gru_wgrad_kernel dW_ih, dW_hh, db_ih, db_hh = row-tile GEMMs over (dgi, x) and (dgh, hm) -> slabs
+#include "mlp_core.h"
+
+#define GS 193              // LDS row stride of the GRU weights (k-major: sW[k*GS + g], g < 192)
+#define NG 192
+#define N_SCR 6             // scratch components
+#define SCR_HM 0
+#define SCR_R 1
+#define SCR_Z 2
+#define SCR_N 3
+#define SCR_GHN 4
+#define SCR_HS 5
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---- LDS maps -----------------------------------------------------------------------------------------
+struct GruLds {
+  int wih, whh, wh, bih, bhh, nw, nb, bh, tiles, wave_stride, total;
+};
+__host__ __device__ inline GruLds gru_lds(int n_waves, int wave_rows) {
+  GruLds m;
+  int p = 0;
+  m.wih = p; p = al4(p + HID * GS);
+  m.whh = p; p = al4(p + HID * GS);
+  m.wh = p; p = al4(p + HID * HP);
+  m.bih = p; p += NG; m.bhh = p; p += NG;
+  m.nw = p; p += HID; m.nb = p; p += HID;
+  m.bh = p; p += 32;
+  m.tiles = p;
+  m.wave_stride = al4(wave_rows * TP);
+  p += n_waves * m.wave_stride;
+  m.total = p;
+  return m;
+}
+__host__ __device__ inline int al4(int p);
+
+// stage W[g][k] (row-major [192][64]) -> dst[k*GS + g]; batched unconditional 16-byte loads
+__device__ __forceinline__ void stage_gru_weight(float *dst, const float *__restrict__ src) {
+  const int nthr = blockDim.x, tid = threadIdx.x, n4 = NG * HID / 4;
+  for (int i0 = 0; i0 < n4; i0 += 8 * nthr) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = reinterpret_cast<const float4 *>(src)[min(i0 + j * nthr + tid, n4 - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j * nthr + tid;
+      if (i < n4) {
+        const int g = i >> 4, k = (i & 15) << 2;
+        dst[(k + 0) * GS + g] = v[j].x; dst[(k + 1) * GS + g] = v[j].y;
+        dst[(k + 2) * GS + g] = v[j].z; dst[(k + 3) * GS + g] = v[j].w;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_gru_all(float *lds, const GruLds &m, const float *__restrict__ params, const NetOff &o, int A,
+                                              bool need_ih, bool need_head) {
+  if (need_ih) stage_gru_weight(lds + m.wih, params + o.gru_wih);
+  stage_gru_weight(lds + m.whh, params + o.gru_whh);
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  for (int e = tid; e < NG; e += nthr) { lds[m.bih + e] = params[o.gru_bih + e]; lds[m.bhh + e] = params[o.gru_bhh + e]; }
+  for (int e = tid; e < HID; e += nthr) { lds[m.nw + e] = params[o.rn_w + e]; lds[m.nb + e] = params[o.rn_b + e]; }
+  if (need_head) {
+    for (int e = tid; e < 32; e += nthr) lds[m.bh + e] = e < A ? params[o.bh + e] : 0.f;
+    for (int e = tid; e < HID * 32; e += nthr) {
+      const int a = e >> 6, k = e & 63;
+      lds[m.wh + k * HP + a] = (a < A) ? params[o.wh + a * HID + k] : 0.f;
+    }
+  }
+}
+
+// row-major state [row][64] <-> accumulator layout (lane = sequence, registers = 32 of its 64 features)
+__device__ __forceinline__ void load_state_rowmajor(f32x16 (&h)[2], const float *__restrict__ src, int64_t row, bool ok, int half) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4 *>(src + row * HID + 32 * t + 8 * q + 4 * half);
+      h[t][4 * q + 0] = v.x; h[t][4 * q + 1] = v.y; h[t][4 * q + 2] = v.z; h[t][4 * q + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void store_state_rowmajor(float *__restrict__ dst, int64_t row, const f32x16 (&h)[2], bool ok, int half) {
+  if (!ok) return;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      *reinterpret_cast<float4 *>(dst + row * HID + 32 * t + 8 * q + 4 * half) =
+          make_float4(h[t][4 * q + 0], h[t][4 * q + 1], h[t][4 * q + 2], h[t][4 * q + 3]);
+}
+// feature-major [64][ld] <-> accumulator layout: for a fixed register the 32 lanes of a half touch 128 contiguous bytes
+__device__ __forceinline__ void load_fm(f32x16 (&v)[2], const float *__restrict__ src, int64_t ld, int64_t col, bool ok, int half) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[t][r] = ok ? src[(int64_t)(32 * t + ROWMAP(r, half)) * ld + col] : 0.f;
+}
+__device__ __forceinline__ void store_fm(float *__restrict__ dst, int64_t ld, int64_t col, const f32x16 (&v)[2], bool ok, int half) {
+  if (!ok) return;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(int64_t)(32 * t + ROWMAP(r, half)) * ld + col] = v[t][r];
+}
+__device__ __forceinline__ void regs_to_tile64(float *tile, const f32x16 (&v)[2], int l31, int half) {
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[(32 * t + ROWMAP(r, half)) * TP + l31] = v[t][r];
+}
+
+// LayerNorm(64) statistics of an accumulator-layout vector
+__device__ __forceinline__ void ln_stats(const f32x16 (&v)[2], float &mean, float &rstd) {
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += v[t][r];
+  mean = xhalf_sum(s) * (1.f / HID);
+  float q = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float c = v[t][r] - mean; q += c * c; }
+  rstd = 1.0f / sqrtf(xhalf_sum(q) * (1.f / HID) + LN_EPS);
+}
+
+// head on a tile of normalised states (affine applied on read): z^T[a][s]
+__device__ __forceinline__ f32x16 gru_head(const float *lds, const GruLds &m, const float *tN, int l31, int half) {
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 b = *reinterpret_cast<const float4 *>(lds + m.bh + 8 * q + 4 * half);
+    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+  }
+  const float *sW = lds + m.wh, *sG = lds + m.nw, *sB = lds + m.nb;
+#pragma unroll 16
+  for (int kk = 0; kk < HID / 2; ++kk) {
+    const int k = 2 * kk + half;
+    acc = mfma(sW[k * HP + l31], tN[k * TP + l31] * sG[k] + sB[k], acc);
+  }
+  return acc;
+}
+
+// ---- one GRU cell step for a tile: gates from x (B operand straight from feature-major HBM) and hm (LDS tile) ----
+struct CellOut { f32x16 r[2], z[2], n[2], ghn[2]; };
+
+__device__ __forceinline__ void gru_cell(CellOut &c, const float *lds, const GruLds &m, const float *__restrict__ xT, int64_t ldx,
+                                         int64_t col, bool ok, const float *tHm, int l31, int half) {
+  f32x16 arz[4], ain[2], ahn[2];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = *reinterpret_cast<const float4 *>(lds + m.bih + 32 * t + 8 * q + 4 * half);
+      const float4 b = *reinterpret_cast<const float4 *>(lds + m.bhh + 32 * t + 8 * q + 4 * half);
+      arz[t][4 * q + 0] = a.x + b.x; arz[t][4 * q + 1] = a.y + b.y; arz[t][4 * q + 2] = a.z + b.z; arz[t][4 * q + 3] = a.w + b.w;
+    }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 a = *reinterpret_cast<const float4 *>(lds + m.bih + 128 + 32 * t + 8 * q + 4 * half);
+      const float4 b = *reinterpret_cast<const float4 *>(lds + m.bhh + 128 + 32 * t + 8 * q + 4 * half);
+      ain[t][4 * q + 0] = a.x; ain[t][4 * q + 1] = a.y; ain[t][4 * q + 2] = a.z; ain[t][4 * q + 3] = a.w;
+      ahn[t][4 * q + 0] = b.x; ahn[t][4 * q + 1] = b.y; ahn[t][4 * q + 2] = b.z; ahn[t][4 * q + 3] = b.w;
+    }
+  const float *sI = lds + m.wih, *sH = lds + m.whh;
+  // B operand of W_ih.x: lane (s, khalf) needs x[k = 2kk+khalf][s] = one coalesced 128-B segment per half -> registers
+  float bx[HID / 2];
+#pragma unroll
+  for (int kk = 0; kk < HID / 2; ++kk) bx[kk] = ok ? xT[(int64_t)(2 * kk + half) * ldx + col] : 0.f;
+#pragma unroll 4
+  for (int kk = 0; kk < HID / 2; ++kk) {
+    const int k = 2 * kk + half;
+    const float bxx = bx[kk], bh = tHm[k * TP + l31];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      arz[t] = mfma(sI[k * GS + 32 * t + l31], bxx, arz[t]);
+      arz[t] = mfma(sH[k * GS + 32 * t + l31], bh, arz[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ain[t] = mfma(sI[k * GS + 128 + 32 * t + l31], bxx, ain[t]);
+      ahn[t] = mfma(sH[k * GS + 128 + 32 * t + l31], bh, ahn[t]);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      c.r[t][r] = sigmoidf_(arz[t][r]);
+      c.z[t][r] = sigmoidf_(arz[2 + t][r]);
+      c.ghn[t][r] = ahn[t][r];
+      c.n[t][r] = tanhf(ain[t][r] + c.r[t][r] * ahn[t][r]);
+    }
+}
+
+// ---- forward kernel -----------------------------------------------------------------------------------
+struct GruFwdArgs {
+  const float *params;
+  NetOff off;
+  GruLds map;
+  const float *xT;            // [64][B] trunk features, B = L*Nc, column t*Nc + c
+  const float *h0;            // [.][64] row-major initial states
+  const int32_t *h0_rows;     // [Nc] or NULL (identity)
+  const float *masks;         // buffer-order masks, indexed by rows[t*Nc + c] (NULL rows = identity)
+  const int32_t *rows;
+  int L, Nc, A, head_mode;    // head_mode 0: none, 1: out[B][A], 2: sample (actions/logp [B])
+  float *h_last;              // [Nc][64] row-major or NULL
+  float *scratch;             // [6][L][64][Nc] or NULL (training)
+  float *out;
+  const float *avail;         // [B][A] minibatch order, or NULL
+  float *actions, *logp;
+  int deterministic;
+  uint64_t seed, counter;
+  const uint64_t *counter_dev;
+};
+
+__global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  const GruLds &m = p.map;
+  const int n_waves = blockDim.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  stage_gru_all(lds, m, p.params, p.off, p.A, true, p.head_mode != 0);
+  __syncthreads();
+  float *tHm = lds + m.tiles + wave * m.wave_stride;     // [64][TP] masked previous state (B operand)
+  float *tN = tHm + HID * TP;                            // [64][TP] normalised state (head input)   (head modes only)
+  float *tZ = tN + HID * TP;                             // [32][TP] head output [s][a]               (head modes only)
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int n_tiles = (p.Nc + TS - 1) / TS;
+  for (int tile = blockIdx.x * n_waves + wave; tile < n_tiles; tile += gridDim.x * n_waves) {
+    const int c = tile * TS + l31;
+    const bool ok = c < p.Nc;
+    const int n_valid = min(TS, p.Nc - tile * TS);
+    f32x16 h[2];
+    load_state_rowmajor(h, p.h0, ok ? (p.h0_rows ? (int64_t)p.h0_rows[c] : (int64_t)c) : 0, ok, half);
+    for (int t = 0; t < p.L; ++t) {
+      const int64_t col = (int64_t)t * p.Nc + c;
+      float mk = 0.f;
+      if (ok) mk = p.masks[p.rows ? (int64_t)p.rows[col] : col];
+      f32x16 hm[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hm[tt][r] = h[tt][r] * mk;
+      regs_to_tile64(tHm, hm, l31, half);
+      wave_lds_sync();
+      CellOut co;
+      gru_cell(co, lds, m, p.xT, B, col, ok, tHm, l31, half);
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h[tt][r] = (1.f - co.z[tt][r]) * co.n[tt][r] + co.z[tt][r] * hm[tt][r];
+      if (p.scratch) {
+        const int64_t comp = (int64_t)p.L * HID * p.Nc;
+        float *base = p.scratch + (int64_t)t * HID * p.Nc;
+        store_fm(base + SCR_HM * comp, p.Nc, c, hm, ok, half);
+        store_fm(base + SCR_R * comp, p.Nc, c, co.r, ok, half);
+        store_fm(base + SCR_Z * comp, p.Nc, c, co.z, ok, half);
+        store_fm(base + SCR_N * comp, p.Nc, c, co.n, ok, half);
+        store_fm(base + SCR_GHN * comp, p.Nc, c, co.ghn, ok, half);
+        store_fm(base + SCR_HS * comp, p.Nc, c, h, ok, half);
+      }
+      if (p.head_mode != 0) {
+        float mean, rstd;
+        ln_stats(h, mean, rstd);
+        f32x16 xh[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xh[tt][r] = (h[tt][r] - mean) * rstd;
+        regs_to_tile64(tN, xh, l31, half);
+        wave_lds_sync();
+        const f32x16 z = gru_head(lds, m, tN, l31, half);
+        head_to_tile(tZ, z, p.A, l31, half);
+        wave_lds_sync();
+        const int64_t row0 = (int64_t)t * p.Nc + tile * TS;
+        if (p.head_mode == 1) {
+          for (int e = lane; e < n_valid * p.A; e += WAVE) {
+            const int s = e / p.A, a = e - s * p.A;
+            p.out[row0 * p.A + e] = tZ[s * TP + a];
+          }
+        } else if (lane < n_valid) {
+          const int64_t i = row0 + lane;
+          const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+          float action, logp;
+          categorical_act_lane(tZ + lane * TP, p.A, p.avail ? p.avail + i * p.A : nullptr, p.deterministic != 0, p.seed, ctr,
+                               (uint64_t)i, action, logp);
+          p.actions[i] = action;
+          p.logp[i] = logp;
+        }
+      }
+      wave_lds_sync();
+    }
+    if (p.h_last) store_state_rowmajor(p.h_last, c, h, ok, half);
+  }
+}
+
+// ---- backward kernel ----------------------------------------------------------------------------------
+struct GruBwdArgs {
+  const float *params;
+  NetOff off;
+  GruLds map;
+  const float *scratch;       // from the forward: [6][L][64][Nc]
+  const float *masks;
+  const int32_t *rows;
+  int L, Nc, A, head;         // head 1: actor loss, 2: critic loss
+  // loss inputs (buffer order, indexed through rows)
+  const float *avail, *actions, *old_logp, *adv, *active, *v_old, *returns, *vn_state;
+  const double *mb_moments;
+  mappo_ppo_cfg cfg;
+  // outputs
+  float *dxT;                 // [64][B]
+  float *dgiT;                // [192][B]  (r, z, n parts of d gi; the r, z parts of d gh are identical)
+  float *dghnT;               // [64][B]   n part of d gh
+  float *slabs;               // [gridDim.x][slab_stride]; this kernel writes head + rnn.norm columns at slab_col0 + offsets
+  int64_t slab_stride, slab_col0;
+  double *partials;           // [gridDim.x][4]
+};
+
+__global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ double red_smem[16 * 4];
+  const GruLds &m = p.map;
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
+  const int A = p.A;
+  stage_gru_all(lds, m, p.params, o, A, true, true);
+  __syncthreads();
+  float *tG = lds + m.tiles;                 // [192][TP]  d gi / d gh (B operand of the W^T products)
+  float *tN = tG + NG * TP;                  // [64][TP]   normalised state, then scratch
+  float *tZ = tN + HID * TP;                 // [32][TP]   head output / gradient [s][a]
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t comp = (int64_t)p.L * HID * p.Nc;
+  const LossScales ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
+  double lacc[4] = {0.0, 0.0, 0.0, 0.0};
+  f32x16 gWh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gWh[i][r] = 0.f;
+  float gBh = 0.f, gNw = 0.f, gNb = 0.f;
+
+  const int n_tiles = (p.Nc + TS - 1) / TS;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int c = tile * TS + l31;
+    const bool ok = c < p.Nc;
+    f32x16 carry[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) carry[tt][r] = 0.f;
+    for (int t = p.L - 1; t >= 0; --t) {
+      const int64_t col = (int64_t)t * p.Nc + c;
+      const float *sb = p.scratch + (int64_t)t * HID * p.Nc;
+      const int64_t brow = ok ? (p.rows ? (int64_t)p.rows[col] : col) : 0;
+      // ---- y = LayerNorm(h'_t) -> head -> loss gradient at the head ----
+      f32x16 hs[2];
+      load_fm(hs, sb + SCR_HS * comp, p.Nc, c, ok, half);
+      float mean, rstd;
+      ln_stats(hs, mean, rstd);
+      f32x16 xh[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xh[tt][r] = (hs[tt][r] - mean) * rstd;
+      regs_to_tile64(tN, xh, l31, half);
+      wave_lds_sync();
+      const f32x16 z = gru_head(lds, m, tN, l31, half);
+      if (p.head == 1) {
+        head_to_tile(tZ, z, A, l31, half);
+        wave_lds_sync();
+        if (lane < TS) {
+          float *zl = tZ + lane * TP;
+          if (ok) {
+            uint32_t dead = 0u;
+            if (p.avail) {
+              const float *av = p.avail + brow * A;
+              for (int a = 0; a < A; ++a) dead |= (av[a] == 0.f ? 1u : 0u) << a;
+            }
+            actor_loss_lane(zl, A, dead, (int)p.actions[brow], p.old_logp[brow], p.adv[brow], p.active[brow], p.cfg, ls.scale_pi, lacc);
+          } else {
+            for (int a = 0; a < A; ++a) zl[a] = 0.f;
+          }
+        }
+      } else if (lane < TS) {
+        float dvv = 0.f;
+        if (ok) dvv = critic_loss_lane(z[0], p.v_old[brow], p.returns[brow], p.active[brow], p.cfg, ls, lacc);
+        tZ[lane * TP] = dvv;
+      }
+      wave_lds_sync();
+      // ---- head weight / bias gradients and d y = Wh^T dz ----
+      f32x16 dH[2];
+      {
+        const float *sG = lds + m.nw, *sBt = lds + m.nb;
+        const float g0 = sG[l31], c0 = sBt[l31], g1 = sG[32 + l31], c1 = sBt[32 + l31];
+        float bsum = 0.f;
+#pragma unroll 4
+        for (int ss = 0; ss < TS / 2; ++ss) {
+          const int s = 2 * ss + half;
+          const float av = (l31 < A) ? tZ[s * TP + l31] : 0.f;
+          bsum += av;
+          gWh[0] = mfma(av, tN[l31 * TP + s] * g0 + c0, gWh[0]);
+          gWh[1] = mfma(av, tN[(32 + l31) * TP + s] * g1 + c1, gWh[1]);
+        }
+        gBh += xhalf_sum(bsum);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dH[tt][r] = 0.f;
+        const float *sW = lds + m.wh;
+        for (int kk = 0; kk < (A + 1) / 2; ++kk) {
+          const int a = 2 * kk + half;
+          const float b = (a < A) ? tZ[l31 * TP + a] : 0.f;
+          dH[0] = mfma(sW[l31 * HP + a], b, dH[0]);
+          dH[1] = mfma(sW[(32 + l31) * HP + a], b, dH[1]);
+        }
+      }
+      wave_lds_sync();
+      // ---- LayerNorm backward (rnn.norm): row sums through the tN tile, then d h' ----
+      regs_to_tile64(tN, dH, l31, half);
+      wave_lds_sync();
+      { float s0 = 0.f; for (int j = 0; j < TS; ++j) s0 += tN[lane * TP + j]; gNb += s0; }
+      wave_lds_sync();
+      float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int f = 32 * tt + ROWMAP(r, half);
+          tN[f * TP + l31] = dH[tt][r] * xh[tt][r];
+          const float dxh = dH[tt][r] * lds[m.nw + f];
+          dH[tt][r] = dxh;
+          m1 += dxh; m2 += dxh * xh[tt][r];
+        }
+      wave_lds_sync();
+      { float s0 = 0.f; for (int j = 0; j < TS; ++j) s0 += tN[lane * TP + j]; gNw += s0; }
+      wave_lds_sync();
+      m1 = xhalf_sum(m1) * (1.f / HID);
+      m2 = xhalf_sum(m2) * (1.f / HID);
+      // d h'_t = LN backward + carry from step t+1
+      f32x16 dh[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dh[tt][r] = rstd * (dH[tt][r] - m1 - xh[tt][r] * m2) + carry[tt][r];
+      // ---- cell backward ----
+      f32x16 hm[2], gr[2], gz[2], gn[2], ghn[2];
+      load_fm(hm, sb + SCR_HM * comp, p.Nc, c, ok, half);
+      load_fm(gr, sb + SCR_R * comp, p.Nc, c, ok, half);
+      load_fm(gz, sb + SCR_Z * comp, p.Nc, c, ok, half);
+      load_fm(gn, sb + SCR_N * comp, p.Nc, c, ok, half);
+      load_fm(ghn, sb + SCR_GHN * comp, p.Nc, c, ok, half);
+      f32x16 d_r[2], d_z[2], d_n[2], d_hn[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float dhh = dh[tt][r], zz = gz[tt][r], nn = gn[tt][r], rr = gr[tt][r];
+          const float dn_pre = dhh * (1.f - zz) * (1.f - nn * nn);
+          d_n[tt][r] = dn_pre;
+          d_hn[tt][r] = dn_pre * rr;
+          d_r[tt][r] = dn_pre * ghn[tt][r] * rr * (1.f - rr);
+          d_z[tt][r] = dhh * (hm[tt][r] - nn) * zz * (1.f - zz);
+        }
+      // scratch for the weight-gradient GEMMs
+      store_fm(p.dgiT, B, col, d_r, ok, half);
+      store_fm(p.dgiT + (int64_t)HID * B, B, col, d_z, ok, half);
+      store_fm(p.dgiT + (int64_t)2 * HID * B, B, col, d_n, ok, half);
+      store_fm(p.dghnT, B, col, d_hn, ok, half);
+      // tG <- d gi  [g][s]
+      regs_to_tile64(tG, d_r, l31, half);
+      regs_to_tile64(tG + HID * TP, d_z, l31, half);
+      regs_to_tile64(tG + 2 * HID * TP, d_n, l31, half);
+      wave_lds_sync();
+      // d x_t = W_ih^T . d gi
+      f32x16 dx[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[tt][r] = 0.f;
+      {
+        const float *sI = lds + m.wih;
+#pragma unroll 4
+        for (int gg = 0; gg < NG / 2; ++gg) {
+          const int g = 2 * gg + half;
+          const float b = tG[g * TP + l31];
+          dx[0] = mfma(sI[l31 * GS + g], b, dx[0]);
+          dx[1] = mfma(sI[(32 + l31) * GS + g], b, dx[1]);
+        }
+      }
+      store_fm(p.dxT, B, col, dx, ok, half);
+      wave_lds_sync();
+      // tG n-rows <- d gh_n ; d hm = W_hh^T . d gh
+      regs_to_tile64(tG + 2 * HID * TP, d_hn, l31, half);
+      wave_lds_sync();
+      f32x16 dhm[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dhm[tt][r] = 0.f;
+      {
+        const float *sH = lds + m.whh;
+#pragma unroll 4
+        for (int gg = 0; gg < NG / 2; ++gg) {
+          const int g = 2 * gg + half;
+          const float b = tG[g * TP + l31];
+          dhm[0] = mfma(sH[l31 * GS + g], b, dhm[0]);
+          dhm[1] = mfma(sH[(32 + l31) * GS + g], b, dhm[1]);
+        }
+      }
+      float mk = 0.f;
+      if (ok) mk = p.masks[brow];
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) carry[tt][r] = (dhm[tt][r] + dh[tt][r] * gz[tt][r]) * mk;
+      wave_lds_sync();
+    }
+  }
+  // ---- loss partial sums + this workgroup's slab (head and rnn.norm columns only) ----
+  block_sum<4>(lacc, red_smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.partials[(size_t)blockIdx.x * 4 + k] = lacc[k];
+  }
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = ROWMAP(r, half);
+      if (a < A) slab[o.wh + a * HID + 32 * tj + l31] = gWh[tj][r];
+    }
+  if (half == 0 && l31 < A) slab[o.bh + l31] = gBh;
+  slab[o.rn_w + lane] = gNw;
+  slab[o.rn_b + lane] = gNb;
+}
+
+// ---- weight-gradient kernel ---------------------------------------------------------------------------
+// Workgroup = 4 waves = 4 roles over the same row tiles: role = (matrix ih|hh) x (gate rows 0..95 | 96..191).
+// dW[g][k] = sum_rows dG[g][row] * in[k][row]:  A operand = dG tile read transposed (lanes <-> g), B = input tile.
+struct GruWgArgs {
+  NetOff off;
+  const float *xT;            // [64][B]
+  const float *scratch;       // hm at component SCR_HM: [L][64][Nc]
+  const float *dgiT, *dghnT;
+  int L, Nc;
+  float *slabs;
+  int64_t slab_stride, slab_col0;
+};
+
+__global__ __launch_bounds__(256, 1) void gru_wgrad_kernel(GruWgArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (WAVE - 1), role = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  const int mat = role >> 1, ghalf = role & 1;              // mat 0: W_ih (x), 1: W_hh (hm)
+  float *tA = lds + role * ((96 + HID) * TP);                // [96][TP] dG rows of this role
+  float *tB = tA + 96 * TP;                                  // [64][TP] input tile
+  const int64_t B = (int64_t)p.L * p.Nc;
+  f32x16 acc[3][2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bacc0 = 0.f, bacc1 = 0.f;                            // bias grads: rows lane and 64 + (lane & 31)
+  const int ct = (p.Nc + TS - 1) / TS;
+  const int n_tiles = p.L * ct;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int t = tile / ct, c0 = (tile - t * ct) * TS;
+    const int nv = min(TS, p.Nc - c0);
+    const int64_t col0 = (int64_t)t * p.Nc + c0;
+    // stage: 96 gate rows (global row g_src) and 64 input rows, 32 columns each; two rows per wave instruction
+    for (int e = lane; e < 96 * TS; e += WAVE) {
+      const int gl = e >> 5, s = e & 31;
+      const int g = 96 * ghalf + gl;
+      const float *src = (mat == 1 && g >= 128) ? p.dghnT + (int64_t)(g - 128) * B : p.dgiT + (int64_t)g * B;
+      tA[gl * TP + s] = (s < nv) ? src[col0 + s] : 0.f;
+    }
+    const float *inb = (mat == 0) ? p.xT : p.scratch + (int64_t)SCR_HM * p.L * HID * p.Nc + (int64_t)t * HID * p.Nc;
+    const int64_t ldi = (mat == 0) ? B : p.Nc;
+    const int64_t ci = (mat == 0) ? col0 : c0;
+    for (int e = lane; e < HID * TS; e += WAVE) {
+      const int k = e >> 5, s = e & 31;
+      tB[k * TP + s] = (s < nv) ? inb[(int64_t)k * ldi + ci + s] : 0.f;
+    }
+    wave_lds_sync();
+#pragma unroll 2
+    for (int ss = 0; ss < TS / 2; ++ss) {
+      const int s = 2 * ss + half;
+      const float b0 = tB[l31 * TP + s], b1 = tB[(32 + l31) * TP + s];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float a = tA[(32 * i + l31) * TP + s];
+        acc[i][0] = mfma(a, b0, acc[i][0]);
+        acc[i][1] = mfma(a, b1, acc[i][1]);
+      }
+    }
+    { float s0 = 0.f; for (int j = 0; j < TS; ++j) s0 += tA[lane * TP + j]; bacc0 += s0; }
+    if (lane < 32) { float s1 = 0.f; for (int j = 0; j < TS; ++j) s1 += tA[(64 + lane) * TP + j]; bacc1 += s1; }
+    wave_lds_sync();
+  }
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
+  const int woff = (mat == 0) ? p.off.gru_wih : p.off.gru_whh, boff = (mat == 0) ? p.off.gru_bih : p.off.gru_bhh;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int g = 96 * ghalf + 32 * i + ROWMAP(r, half), k = 32 * j + l31;
+        slab[woff + g * HID + k] = acc[i][j][r];
+      }
+  slab[boff + 96 * ghalf + lane] = bacc0;
+  if (lane < 32) slab[boff + 96 * ghalf + 64 + lane] = bacc1;
+}
+
+// ---- host ---------------------------------------------------------------------------------------------
+#define LDS_LIMIT (160 * 1024)
+#define LDS_DYN_MAX (LDS_LIMIT - 1024)
+#define NUM_CU 256
+
+static int check_rec(const mappo_net_desc *d, const char *who) {
+  MAPPO_REQUIRE(d && d->recurrent, "%s: needs a recurrent network descriptor", who);
+  MAPPO_REQUIRE(d->hidden == HID, "%s: hidden_size %d unsupported", who, d->hidden);
+  MAPPO_REQUIRE(d->out_dim >= 1 && d->out_dim <= MAPPO_MAX_ACTIONS, "%s: out_dim %d", who, d->out_dim);
+  return MAPPO_OK;
+}
+
+template <typename K>
+static int raise_lds(K kernel, const char *who) {
+  hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+  if (e != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  return MAPPO_OK;
+}
+
+extern "C" int64_t mappo_gru_scratch_floats(int32_t L, int32_t Nc) { return (int64_t)N_SCR * L * HID * Nc; }
+
+extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc, const float *xT, const float *h0,
+                                 const int32_t *h0_rows, const float *masks, const int32_t *rows, int32_t L, int32_t Nc,
+                                 float *h_last, float *scratch, int32_t head_mode, float *out, const float *avail,
+                                 int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
+                                 float *actions, float *logp, mappo_stream_t stream) {
+  if (int rc = check_rec(desc, "gru_forward")) return rc;
+  MAPPO_REQUIRE(params && xT && h0 && masks && L > 0 && Nc > 0, "gru_forward: bad arguments");
+  MAPPO_REQUIRE(head_mode >= 0 && head_mode <= 2, "gru_forward: head_mode %d", head_mode);
+  MAPPO_REQUIRE(head_mode != 1 || out, "gru_forward: out required");
+  MAPPO_REQUIRE(head_mode != 2 || (actions && logp), "gru_forward: actions/logp required");
+  MAPPO_CLEAR_STICKY();
+  GruFwdArgs a = {};
+  a.params = params; a.off = net_offsets(*desc); a.xT = xT; a.h0 = h0; a.h0_rows = h0_rows; a.masks = masks; a.rows = rows;
+  a.L = L; a.Nc = Nc; a.A = desc->out_dim; a.head_mode = head_mode; a.h_last = h_last; a.scratch = scratch; a.out = out;
+  a.avail = avail; a.actions = actions; a.logp = logp; a.deterministic = deterministic; a.seed = seed; a.counter = counter;
+  a.counter_dev = counter_dev;
+  const int n_tiles = (Nc + TS - 1) / TS;
+  int nw = head_mode ? 2 : 4;
+  while (nw > 1 && n_tiles < nw) nw >>= 1;
+  const int wave_rows = head_mode ? (HID + HID + TS) : HID;
+  a.map = gru_lds(nw, wave_rows);
+  const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_forward: needs %zu B of LDS", lds_bytes);
+  static bool attr = false;
+  if (!attr) { if (int rc = raise_lds(gru_fwd_kernel, "gru_forward")) return rc; attr = true; }
+  int nb = (n_tiles + nw - 1) / nw;
+  if (nb > NUM_CU) nb = NUM_CU;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(nb), dim3(WAVE * nw), lds_bytes, as_stream(stream), a);
+  MAPPO_CHECK_LAUNCH("gru_forward");
+  return MAPPO_OK;
+}
+
+extern "C" int32_t mappo_gru_backward_slabs(int32_t Nc) {
+  const int n_tiles = (Nc + TS - 1) / TS;
+  return n_tiles < NUM_CU ? n_tiles : NUM_CU;
+}
+
+extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *desc, const float *scratch, const float *masks,
+                                  const int32_t *rows, int32_t L, int32_t Nc, int32_t head, const float *avail,
+                                  const float *actions, const float *old_logp, const float *adv, const float *active,
+                                  const float *v_old, const float *returns, const float *vn_state, const double *mb_moments,
+                                  const mappo_ppo_cfg *cfg, float *dxT, float *dgiT, float *dghnT, float *slabs,
+                                  int64_t slab_stride, int64_t slab_col0, double *partials, mappo_stream_t stream) {
+  if (int rc = check_rec(desc, "gru_backward")) return rc;
+  MAPPO_REQUIRE(params && scratch && masks && active && mb_moments && cfg && dxT && dgiT && dghnT && slabs && partials && L > 0 && Nc > 0,
+                "gru_backward: bad arguments");
+  MAPPO_REQUIRE(head == 1 || head == 2, "gru_backward: head %d", head);
+  MAPPO_REQUIRE(head != 1 || (actions && old_logp && adv), "gru_backward: actor loss inputs");
+  MAPPO_REQUIRE(head != 2 || (v_old && returns && (!cfg->use_valuenorm || vn_state)), "gru_backward: critic loss inputs");
+  MAPPO_CLEAR_STICKY();
+  GruBwdArgs a = {};
+  a.params = params; a.off = net_offsets(*desc); a.scratch = scratch; a.masks = masks; a.rows = rows; a.L = L; a.Nc = Nc;
+  a.A = desc->out_dim; a.head = head; a.avail = avail; a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.active = active;
+  a.v_old = v_old; a.returns = returns; a.vn_state = vn_state; a.mb_moments = mb_moments; a.cfg = *cfg; a.dxT = dxT; a.dgiT = dgiT;
+  a.dghnT = dghnT; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0; a.partials = partials;
+  MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru_backward: slab column range");
+  a.map = gru_lds(1, NG + HID + TS);
+  const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_backward: needs %zu B of LDS", lds_bytes);
+  static bool attr = false;
+  if (!attr) { if (int rc = raise_lds(gru_bwd_kernel, "gru_backward")) return rc; attr = true; }
+  const int nb = mappo_gru_backward_slabs(Nc);
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(WAVE), lds_bytes, as_stream(stream), a);
+  MAPPO_CHECK_LAUNCH("gru_backward");
+  return MAPPO_OK;
+}
+
+extern "C" int32_t mappo_gru_wgrad_slabs(int32_t L, int32_t Nc) {
+  const int n_tiles = L * ((Nc + TS - 1) / TS);
+  return n_tiles < NUM_CU ? n_tiles : NUM_CU;
+}
+
+extern "C" int mappo_gru_wgrad(const mappo_net_desc *desc, const float *xT, const float *scratch, const float *dgiT,
+                               const float *dghnT, int32_t L, int32_t Nc, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                               mappo_stream_t stream) {
+  if (int rc = check_rec(desc, "gru_wgrad")) return rc;
+  MAPPO_REQUIRE(xT && scratch && dgiT && dghnT && slabs && L > 0 && Nc > 0, "gru_wgrad: bad arguments");
+  MAPPO_CLEAR_STICKY();
+  GruWgArgs a = {};
+  a.off = net_offsets(*desc); a.xT = xT; a.scratch = scratch; a.dgiT = dgiT; a.dghnT = dghnT; a.L = L; a.Nc = Nc;
+  a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
+  MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru_wgrad: slab column range");
+  const size_t lds_bytes = (size_t)4 * (96 + HID) * TP * sizeof(float);
+  static bool attr = false;
+  if (!attr) { if (int rc = raise_lds(gru_wgrad_kernel, "gru_wgrad")) return rc; attr = true; }
+  const int nb = mappo_gru_wgrad_slabs(L, Nc);
+  hipLaunchKernelGGL(gru_wgrad_kernel, dim3(nb), dim3(256), lds_bytes, as_stream(stream), a);
+  MAPPO_CHECK_LAUNCH("gru_wgrad");
+  return MAPPO_OK;
+}

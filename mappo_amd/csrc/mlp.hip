@@ -31,46 +31,7 @@
 //
 // Limits of this build: hidden == 64, out_dim <= 32, layer_N <= 2, in_dim <= 64 (the K-chunked layer-1 path
 // for wider observations is a separate kernel).
-#include "common.h"
-#include <float.h>
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-#define HID 64
-#define TS 32          // samples per wave tile
-#define TP 33          // tile row stride (floats)
-#define WP 65          // hidden-weight row stride (floats)
-#define HP 33          // head-weight row stride
-#define MAXD 64
-#define LN_EPS 1e-5f
-
-struct NetOff {
-  int fn_w, fn_b, w1, b1, ln1_w, ln1_b;
-  int w2[MAPPO_MAX_LAYER_N], b2[MAPPO_MAX_LAYER_N], ln2_w[MAPPO_MAX_LAYER_N], ln2_b[MAPPO_MAX_LAYER_N];
-  int gru_wih, gru_whh, gru_bih, gru_bhh, rn_w, rn_b;
-  int wh, bh, total;
-};
-
-__host__ __device__ inline NetOff net_offsets(const mappo_net_desc &d) {
-  NetOff o;
-  int p = 0;
-  const int D = d.in_dim, H = d.hidden;
-  o.fn_w = o.fn_b = -1;
-  if (d.use_feature_norm) { o.fn_w = p; p += D; o.fn_b = p; p += D; }
-  o.w1 = p; p += H * D; o.b1 = p; p += H; o.ln1_w = p; p += H; o.ln1_b = p; p += H;
-  for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) {
-    o.w2[l] = o.b2[l] = o.ln2_w[l] = o.ln2_b[l] = -1;
-    if (l < d.layer_N) { o.w2[l] = p; p += H * H; o.b2[l] = p; p += H; o.ln2_w[l] = p; p += H; o.ln2_b[l] = p; p += H; }
-  }
-  o.gru_wih = o.gru_whh = o.gru_bih = o.gru_bhh = o.rn_w = o.rn_b = -1;
-  if (d.recurrent) {
-    o.gru_wih = p; p += 3 * H * H; o.gru_whh = p; p += 3 * H * H; o.gru_bih = p; p += 3 * H; o.gru_bhh = p; p += 3 * H;
-    o.rn_w = p; p += H; o.rn_b = p; p += H;
-  }
-  o.wh = p; p += d.out_dim * H; o.bh = p; p += d.out_dim;
-  o.total = p;
-  return o;
-}
+#include "mlp_core.h"
 
 extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
   if (!desc) return -1;
@@ -87,7 +48,6 @@ struct LdsMap {
   int tiles, x_rows, wave_stride, total;
 };
 
-__host__ __device__ inline int al4(int p) { return (p + 3) & ~3; }
 
 __host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves) {
   LdsMap m;
@@ -109,40 +69,6 @@ __host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves) 
   p += n_waves * m.wave_stride;
   m.total = p;
   return m;
-}
-
-// ------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync() {
-  // The tiles are private to one wavefront and the LDS executes a wave's DS instructions in order; what has to
-  // be prevented is the COMPILER moving a tile read above the tile write that produced it.
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, WAVE); }
-
-// fire-and-forget LDS float add (ds_add_f32): used where exactly one wave adds into a location per phase, so the
-// result does not depend on arrival order
-__device__ __forceinline__ void lds_add(float *p, float v) {
-  (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// row (feature within a 32-row MFMA tile) held by accumulator register `reg` of lane-half `half`
-#define ROWMAP(reg, half) (((reg) & 3) + 8 * ((reg) >> 2) + 4 * (half))
-
-template <bool RELU>
-__device__ __forceinline__ float act_fwd(float z) { return RELU ? fmaxf(z, 0.f) : tanhf(z); }
-
-__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// 4 consecutive features (reg&3 = 0..3) of a per-feature vector in LDS, as one 16-byte read
-__device__ __forceinline__ float4 vec4_of(const float *sV, int t, int q, int half) {
-  return *reinterpret_cast<const float4 *>(sV + 32 * t + 8 * q + 4 * half);
 }
 
 // Workgroup-cooperative staging of one weight matrix: global W[f][k] (row-major, K columns) -> LDS dst[k*stride + f],
@@ -416,30 +342,6 @@ __device__ __forceinline__ f32x16 head_forward(const float *lds, const LdsMap &m
   return acc;
 }
 
-// head output (accumulator layout) -> tZ[s][a]
-__device__ __forceinline__ void head_to_tile(float *tZ, const f32x16 &z, int A, int l31, int half) {
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int a = ROWMAP(r, half);
-    if (a < A) tZ[l31 * TP + a] = z[r];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Philox4x32-10 (counter-based RNG for action sampling)
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t counter, uint64_t index) {
-  uint32_t c0 = (uint32_t)index, c1 = (uint32_t)(index >> 32), c2 = (uint32_t)counter, c3 = (uint32_t)(counter >> 32);
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return c0;
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward kernel.  MODE 0: out[B][A] = head output.   MODE 1: sample/argmax + log-prob (get_actions).
@@ -484,6 +386,22 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
     prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);
     TileStats<LN> st;
     tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
+    if (MODE == 2) {
+      // trunk features (LayerNorm output of the last layer, affine applied) feature-major: out[f][B], the input
+      // layout of the GRU kernels (gru.hip); a register's 32 lanes write one 128-B segment
+      const float *tL = tH + LN * HID * TP, *sG = lds + ln_w_of<LN>(m, LN), *sBt = lds + ln_b_of<LN>(m, LN);
+      if (l31 < n_valid) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int f = 32 * t + ROWMAP(r, half);
+            p.out[(int64_t)f * p.B + base + l31] = tL[f * TP + l31] * sG[f] + sBt[f];
+          }
+      }
+      wave_lds_sync();
+      continue;
+    }
     const f32x16 z = head_forward(lds, m, tH + LN * HID * TP, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN), l31, half);
     head_to_tile(tZ, z, A, l31, half);
     wave_lds_sync();
@@ -494,36 +412,13 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
       }
     } else {
       if (lane < n_valid) {
-        float *zl = tZ + lane * TP;
         const int64_t i = base + lane;
-        const float *av = p.avail ? p.avail + i * A : nullptr;
-        float zmax = -FLT_MAX;
-        for (int a = 0; a < A; ++a) {
-          float za = zl[a];
-          if (av && av[a] == 0.f) { za = -1e10f; zl[a] = za; }
-          zmax = fmaxf(zmax, za);
-        }
-        float se = 0.f;
-        for (int a = 0; a < A; ++a) se += expf(zl[a] - zmax);
-        const float lse = zmax + logf(se);
-        int chosen = 0;
-        if (p.deterministic) {
-          float best = -FLT_MAX;                         // probs.argmax: first maximum
-          for (int a = 0; a < A; ++a) { if (zl[a] > best) { best = zl[a]; chosen = a; } }
-        } else {
-          const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
-          const float u = (float)(philox_u32(p.seed, ctr, (uint64_t)i) >> 8) * (1.0f / 16777216.0f);
-          float c = 0.f;
-          bool found = false;
-          for (int a = 0; a < A; ++a) {
-            const float pa = expf(zl[a] - lse);
-            c += pa;
-            if (!found && pa > 0.f) chosen = a;        // fallback: last action with support
-            if (!found && u < c) { chosen = a; found = true; }
-          }
-        }
-        p.actions[i] = (float)chosen;
-        p.logp[i] = zl[chosen] - lse;
+        const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+        float action, logp;
+        categorical_act_lane(tZ + lane * TP, A, p.avail ? p.avail + i * A : nullptr, p.deterministic != 0, p.seed, ctr, (uint64_t)i,
+                             action, logp);
+        p.actions[i] = action;
+        p.logp[i] = logp;
       }
     }
     wave_lds_sync();
@@ -573,6 +468,8 @@ struct UpdArgs {
   LdsMap map;
   int64_t B;
   int n_regions;             // LDS regions of P floats used for the end-of-kernel reduction (2 when they fit)
+  int p_red;                 // number of leading flat parameters this launch owns (trunk only for HEAD 3)
+  const float *dHT;          // HEAD 3: gradient w.r.t. the trunk output, feature-major [64][B]
   // HEAD 0
   const float *dout;
   // HEAD 1 / 2 (buffer-order arrays, indexed by rows)
@@ -665,7 +562,7 @@ template <int HEAD, bool WIDE>
 __device__ __forceinline__ void prefetch_loss(LossPrefetch &lp, const UpdArgs &p, const RowPrefetch<WIDE> &pf, int lane, int A) {
   lp.f0 = lp.f1 = lp.f2 = lp.f3 = 0.f;
   lp.dead = 0u;
-  if (HEAD == 0 || lane >= pf.n_valid) return;        // lanes 0..31 carry the per-sample loss inputs
+  if (HEAD == 0 || HEAD == 3 || lane >= pf.n_valid) return;        // lanes 0..31 carry the per-sample loss inputs
   const int64_t row = pf.my_row;
   if (HEAD == 1) {
     lp.f0 = p.actions[row]; lp.f1 = p.old_logp[row]; lp.f2 = p.adv[row]; lp.f3 = p.active[row];
@@ -704,15 +601,8 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   float *tZ = tH + (LN + 1) * HID * TP;
 
   // loss constants (HEAD 1/2): denominators are GLOBAL (mb_moments), see ppo_loss.hip
-  float scale_pi = 0.f, scale_v = 0.f, vn_mean = 0.f, vn_sd = 1.f;
-  if (HEAD != 0) {
-    const double sa = p.mb_moments[2], Bg = p.mb_moments[3];
-    const float inv_act = (float)(1.0 / (sa > 0.0 ? sa : 1.0)), inv_B = (float)(1.0 / (Bg > 0.0 ? Bg : 1.0));
-    scale_pi = p.cfg.use_policy_active_masks ? inv_act : inv_B;
-    scale_v = p.cfg.use_value_active_masks ? inv_act : inv_B;
-    const VnStats vn = vn_stats(p.cfg.use_valuenorm ? p.vn_state : nullptr);
-    vn_mean = vn.mean; vn_sd = vn.sd;
-  }
+  LossScales ls = {0.f, 0.f, 0.f, 1.f};
+  if (HEAD == 1 || HEAD == 2) ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
   double lacc[4] = {0.0, 0.0, 0.0, 0.0};   // actor: sum w*min(s1,s2), sum w*H, sum ratio | critic: sum w_v*l
 
   // ---- gradient accumulators (registers, live across the tile loop) ----
@@ -750,7 +640,9 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     STAMP(2);   // trunk forward
 
     // ---- head gradient into tZ[s][a] ----
-    if (HEAD == 0) {
+    if (HEAD == 3) {
+      // nothing: the gradient arrives at the trunk output (loaded below)
+    } else if (HEAD == 0) {
       for (int e = lane; e < TS * A; e += WAVE) {
         const int s = e / A, a = e - s * A;
         tZ[s * TP + a] = (s < n_valid) ? p.dout[base * A + e] : 0.f;
@@ -763,42 +655,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         if (lane < TS) {
           float *zl = tZ + lane * TP;
           if (lane < n_valid) {
-            // distributions.py:64-68 + r_mappo.py:124-141 (same arithmetic as ppo_loss.hip)
-            const int act = (int)cur.f0;
-            const float old_lp = cur.f1, adv = cur.f2, active = cur.f3, clip = p.cfg.clip_param;
-            float zmax = -FLT_MAX;
-            for (int a = 0; a < A; ++a) {
-              float za = zl[a];
-              if (cur.dead & (1u << a)) { za = -1e10f; zl[a] = za; }
-              zmax = fmaxf(zmax, za);
-            }
-            // e_a = exp(z_a - max) is computed once and parked behind the logits (columns 16..31 of the 33-wide row)
-            const bool park = A <= 16;
-            float se = 0.f;
-            for (int a = 0; a < A; ++a) { const float e = expf(zl[a] - zmax); if (park) zl[16 + a] = e; se += e; }
-            const float log_se = logf(se), inv_se = 1.0f / se;
-            float Hent = 0.f;
-            for (int a = 0; a < A; ++a) {
-              const float l_ = (zl[a] - zmax) - log_se;
-              const float pa = (park ? zl[16 + a] : expf(zl[a] - zmax)) * inv_se;
-              Hent -= pa * fmaxf(l_, -FLT_MAX);
-            }
-            const float logp = (zl[act] - zmax) - log_se;
-            const float ratio = expf(logp - old_lp);
-            const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * adv;
-            const float w_pi = p.cfg.use_policy_active_masks ? active : 1.f;
-            const float dlogp = (s1 <= s2) ? -(w_pi * scale_pi) * adv * ratio : 0.f;
-            const float ce = p.cfg.entropy_coef * w_pi * scale_pi;
-            for (int a = 0; a < A; ++a) {
-              const float l_ = (zl[a] - zmax) - log_se;
-              const float pa = (park ? zl[16 + a] : expf(zl[a] - zmax)) * inv_se;
-              float g = dlogp * ((a == act ? 1.f : 0.f) - pa) + ce * pa * (l_ + Hent);
-              if (cur.dead & (1u << a)) g = 0.f;
-              zl[a] = g;
-            }
-            lacc[0] += (double)(w_pi * fminf(s1, s2));
-            lacc[1] += (double)(w_pi * Hent);
-            lacc[2] += (double)ratio;
+            actor_loss_lane(zl, A, cur.dead, (int)cur.f0, cur.f1, cur.f2, cur.f3, p.cfg, ls.scale_pi, lacc);
           } else {
             for (int a = 0; a < A; ++a) zl[a] = 0.f;
           }
@@ -807,35 +664,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         // value loss (r_mappo.py:62-87); the value of sample s is register 0 of lane s (half 0)
         if (lane < TS) {
           float dvv = 0.f;
-          if (lane < n_valid) {
-            const float v = z[0], vo = cur.f0, ret = cur.f1, active = cur.f2, clip = p.cfg.clip_param;
-            const float tgt = p.cfg.use_valuenorm ? (ret - vn_mean) / vn_sd : ret;
-            const float dvc = fminf(fmaxf(v - vo, -clip), clip);
-            const float e_o = tgt - v, e_c = tgt - (vo + dvc);
-            float l_o, l_c, g_o, g_c;
-            if (p.cfg.use_huber_loss) {
-              const float dl = p.cfg.huber_delta;
-              const bool so = fabsf(e_o) <= dl, sc = fabsf(e_c) <= dl;
-              l_o = so ? e_o * e_o * 0.5f : dl * (fabsf(e_o) - dl * 0.5f);
-              l_c = sc ? e_c * e_c * 0.5f : dl * (fabsf(e_c) - dl * 0.5f);
-              g_o = so ? e_o : copysignf(dl, e_o);
-              g_c = sc ? e_c : copysignf(dl, e_c);
-            } else {
-              l_o = e_o * e_o * 0.5f; l_c = e_c * e_c * 0.5f; g_o = e_o; g_c = e_c;
-            }
-            float l, dv;
-            if (p.cfg.use_clipped_value_loss) {
-              const float inside = (fabsf(v - vo) <= clip) ? 1.f : 0.f;
-              const float d_o = -g_o, d_c = -g_c * inside;
-              l = fmaxf(l_o, l_c);
-              dv = (l_o > l_c) ? d_o : ((l_c > l_o) ? d_c : 0.5f * (d_o + d_c));
-            } else {
-              l = l_o; dv = -g_o;
-            }
-            const float w_v = p.cfg.use_value_active_masks ? active : 1.f;
-            dvv = dv * (w_v * scale_v) * p.cfg.value_loss_coef;
-            lacc[0] += (double)(w_v * l);
-          }
+          if (lane < n_valid) dvv = critic_loss_lane(z[0], cur.f0, cur.f1, cur.f2, p.cfg, ls, lacc);
           tZ[lane * TP] = dvv;
         }
       }
@@ -844,7 +673,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     STAMP(3);   // head forward + loss
 
     // ---- (A) head weight / bias gradients:  dWh[a][f] += sum_s dz[s][a] * h_last[f][s] ----
-    {
+    if (HEAD != 3) {
       const float *sG = lds + ln_w_of<LN>(m, LN), *sBt = lds + ln_b_of<LN>(m, LN);
       const float g0 = sG[l31], c0 = sBt[l31], g1 = sG[32 + l31], c1 = sBt[32 + l31];
       float bsum = 0.f;
@@ -864,7 +693,13 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) dH[t][r] = 0.f;
-    {
+    if (HEAD == 3) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (l31 < n_valid) dH[t][r] = p.dHT[(int64_t)(32 * t + ROWMAP(r, half)) * p.B + base + l31];
+    } else {
       const float *sW = lds + m.wh;
       for (int kk = 0; kk < (A + 1) / 2; ++kk) {
         const int a = 2 * kk + half;
@@ -985,7 +820,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   STAMP(11);    // (loop exit)
 
   // ---- loss statistics of this workgroup ----
-  if (HEAD != 0) {
+  if (HEAD == 1 || HEAD == 2) {
     block_sum<4>(lacc, red_smem);
     if (threadIdx.x == 0) {
 #pragma unroll
@@ -995,7 +830,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 
   // ---- reduce the waves' accumulators through LDS (two regions, waves pair up) and write the slab ----
   __syncthreads();
-  const int P = o.total;
+  const int P = p.p_red;
   float *red0 = lds + m.tiles;                     // n_regions * P floats fit in the tile area (checked on the host)
   const int n_reg = p.n_regions;
   for (int round = 0; round < (n_waves + n_reg - 1) / n_reg; ++round) {
@@ -1021,6 +856,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
           for (int l = 0; l < LN; ++l) red_tile(gW2[l][ti][tj], o.w2[l] + row0 * HID + col, HID, true);
         }
       // head: rows a = ROWMAP(r, half) < A only
+      if (HEAD != 3)
 #pragma unroll
       for (int tj = 0; tj < 2; ++tj) {
         float old[16];
@@ -1041,7 +877,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
           vals[n] = gLnW[l + 1]; idx[n] = o.ln2_w[l] + lane; ok[n++] = true;
           vals[n] = gLnB[l + 1]; idx[n] = o.ln2_b[l] + lane; ok[n++] = true;
         }
-        vals[n] = gBh; idx[n] = o.bh + l31; ok[n++] = (half == 0 && l31 < A);
+        vals[n] = gBh; idx[n] = (HEAD != 3) ? o.bh + l31 : 0; ok[n++] = (HEAD != 3 && half == 0 && l31 < A);
         const bool fn = p.desc.use_feature_norm && lane < D;
         vals[n] = gFnW; idx[n] = o.fn_w + lane; ok[n++] = fn;
         vals[n] = gFnB; idx[n] = o.fn_b + lane; ok[n++] = fn;
@@ -1067,7 +903,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int check_desc(const mappo_net_desc *d, const char *who) {
+static int check_desc_common(const mappo_net_desc *d, const char *who) {
   MAPPO_REQUIRE(d, "%s: null desc", who);
   MAPPO_REQUIRE(d->hidden == HID, "%s: hidden_size %d unsupported (kernels are tiled for %d)", who, d->hidden, HID);
   MAPPO_REQUIRE(d->in_dim >= 1 && d->in_dim <= MAXD, "%s: in_dim %d outside [1,%d] (wide-input path not built)", who,
@@ -1076,9 +912,14 @@ static int check_desc(const mappo_net_desc *d, const char *who) {
                 MAPPO_MAX_ACTIONS);
   MAPPO_REQUIRE(d->layer_N >= 0 && d->layer_N <= MAPPO_MAX_LAYER_N, "%s: layer_N %d outside [0,%d]", who, d->layer_N,
                 MAPPO_MAX_LAYER_N);
-  MAPPO_REQUIRE(!d->recurrent, "%s: recurrent networks go through the GRU entry points", who);
   return MAPPO_OK;
 }
+static int check_desc(const mappo_net_desc *d, const char *who) {
+  if (int rc = check_desc_common(d, who)) return rc;
+  MAPPO_REQUIRE(!d->recurrent, "%s: recurrent networks go through mlp_features / gru_* / trunk_backward", who);
+  return MAPPO_OK;
+}
+static int check_desc_trunk(const mappo_net_desc *d, const char *who) { return check_desc_common(d, who); }
 
 #define LDS_LIMIT (160 * 1024)
 #define LDS_STATIC 1024                      // static __shared__ of the kernels (reduction scratch), rounded up
@@ -1138,6 +979,17 @@ extern "C" int mappo_mlp_forward(const float *params, const mappo_net_desc *desc
   return launch_forward<0>(a, as_stream(stream), "mlp_forward");
 }
 
+static int check_desc_trunk(const mappo_net_desc *d, const char *who);
+
+extern "C" int mappo_mlp_features(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
+                                  int64_t B, float *featT, mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(desc, "mlp_features")) return rc;
+  MAPPO_REQUIRE(params && x && featT && B > 0, "mlp_features: bad arguments");
+  FwdArgs a = {};
+  a.params = params; a.x = x; a.rows = rows; a.out = featT; a.desc = *desc; a.B = B;
+  return launch_forward<2>(a, as_stream(stream), "mlp_features");
+}
+
 extern "C" int mappo_actor_act(const float *params, const mappo_net_desc *desc, const float *obs, const float *avail,
                                int64_t B, int32_t deterministic, uint64_t seed, uint64_t counter,
                                const uint64_t *counter_dev, float *actions, float *logp, mappo_stream_t stream) {
@@ -1166,8 +1018,9 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
   a.map = lds_map(d, nw);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
-  a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * a.off.total) ? 2 : 1;
-  MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * a.off.total, "%s: reduction buffer too small", who);
+  a.p_red = (HEAD == 3 && d.recurrent) ? a.off.gru_wih : a.off.total;
+  a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * a.p_red) ? 2 : 1;
+  MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * a.p_red, "%s: reduction buffer too small", who);
   const int nb = mappo_mlp_backward_slabs(a.B);    // every slab the caller sized for is written: grid == that count
   dim3 grid((unsigned)nb), block(WAVE * nw);
 #define UPD2(R, L, W)                                                                                      \
@@ -1201,6 +1054,17 @@ extern "C" int mappo_mlp_backward(const float *params, const mappo_net_desc *des
   a.params = params; a.x = x; a.rows = rows; a.dout = dout; a.slabs = slabs; a.slab_stride = slab_stride;
   a.slab_col0 = slab_col0; a.desc = *desc; a.B = B;
   return launch_update<0>(a, as_stream(stream), "mlp_backward");
+}
+
+extern "C" int mappo_trunk_backward(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
+                                    int64_t B, const float *dHT, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                                    mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(desc, "trunk_backward")) return rc;
+  MAPPO_REQUIRE(params && x && dHT && slabs && B > 0, "trunk_backward: bad arguments");
+  UpdArgs a = {};
+  a.params = params; a.x = x; a.rows = rows; a.dHT = dHT; a.slabs = slabs; a.slab_stride = slab_stride;
+  a.slab_col0 = slab_col0; a.desc = *desc; a.B = B;
+  return launch_update<3>(a, as_stream(stream), "trunk_backward");
 }
 
 extern "C" int64_t mappo_update_partials_bytes(void) { return (int64_t)NUM_CU * 4 * sizeof(double); }
@@ -1260,12 +1124,13 @@ __global__ __launch_bounds__(256) void update_stats_kernel(const double *__restr
   }
 }
 
-extern "C" int mappo_update_stats(const double *actor_partials, const double *critic_partials, int64_t B,
-                                  const double *mb_moments, const mappo_ppo_cfg *cfg, double *stats, mappo_stream_t stream) {
-  MAPPO_REQUIRE(critic_partials && mb_moments && cfg && stats && B > 0, "update_stats: bad arguments");
-  const int nb = mappo_mlp_backward_slabs(B);
+extern "C" int mappo_update_stats(const double *actor_partials, int32_t n_actor, const double *critic_partials,
+                                  int32_t n_critic, const double *mb_moments, const mappo_ppo_cfg *cfg, double *stats,
+                                  mappo_stream_t stream) {
+  MAPPO_REQUIRE(critic_partials && mb_moments && cfg && stats && n_critic > 0 && n_actor >= 0, "update_stats: bad arguments");
   hipLaunchKernelGGL(update_stats_kernel, dim3(1), dim3(256), 0, as_stream(stream), actor_partials, critic_partials,
-                     actor_partials ? nb : 0, nb, mb_moments, cfg->use_policy_active_masks, cfg->use_value_active_masks, stats);
+                     actor_partials ? (int)n_actor : 0, (int)n_critic, mb_moments, cfg->use_policy_active_masks,
+                     cfg->use_value_active_masks, stats);
   MAPPO_CHECK_LAUNCH("update_stats");
   return MAPPO_OK;
 }

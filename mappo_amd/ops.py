@@ -156,10 +156,65 @@ def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_s
     _lib.check(rc, "mappo_critic_update")
 
 
-def update_stats(actor_partials, critic_partials, B, mb_moments, cfg, stats):
-    rc = _lib.load().mappo_update_stats(_ptr(actor_partials, torch.float64, allow_none=True), _ptr(critic_partials, torch.float64),
-                                        int(B), _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(stats, torch.float64), _stream())
+def update_stats(actor_partials, n_actor, critic_partials, n_critic, mb_moments, cfg, stats):
+    rc = _lib.load().mappo_update_stats(_ptr(actor_partials, torch.float64, allow_none=True), int(n_actor),
+                                        _ptr(critic_partials, torch.float64), int(n_critic), _ptr(mb_moments, torch.float64),
+                                        C.byref(cfg), _ptr(stats, torch.float64), _stream())
     _lib.check(rc, "mappo_update_stats")
+
+
+# ---- K9: recurrent layer -------------------------------------------------------------------------
+def mlp_features(params, desc, x, rows, B, featT):
+    rc = _lib.load().mappo_mlp_features(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(B),
+                                        _ptr(featT), _stream())
+    _lib.check(rc, "mappo_mlp_features")
+
+
+def gru_scratch_floats(L, Nc):
+    return int(_lib.load().mappo_gru_scratch_floats(int(L), int(Nc)))
+
+
+def gru_forward(params, desc, featT, h0, h0_rows, masks, rows, L, Nc, h_last=None, scratch=None, head_mode=0, out=None,
+                avail=None, deterministic=False, seed=0, counter=0, counter_dev=None, actions=None, logp=None):
+    rc = _lib.load().mappo_gru_forward(_ptr(params), C.byref(desc), _ptr(featT), _ptr(h0), _ptr(h0_rows, torch.int32, allow_none=True),
+                                       _ptr(masks), _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc),
+                                       _ptr(h_last, allow_none=True), _ptr(scratch, allow_none=True), int(head_mode),
+                                       _ptr(out, allow_none=True), _ptr(avail, allow_none=True), int(bool(deterministic)),
+                                       int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
+                                       _ptr(counter_dev, torch.int64, allow_none=True), _ptr(actions, allow_none=True),
+                                       _ptr(logp, allow_none=True), _stream())
+    _lib.check(rc, "mappo_gru_forward")
+
+
+def gru_backward_slabs(Nc):
+    return int(_lib.load().mappo_gru_backward_slabs(int(Nc)))
+
+
+def gru_backward(params, desc, scratch, masks, rows, L, Nc, head, avail, actions, old_logp, adv, active, v_old, returns, vn_state,
+                 mb_moments, cfg, dxT, dgiT, dghnT, slabs, slab_stride, slab_col0, partials):
+    n = lambda t: _ptr(t, allow_none=True)
+    rc = _lib.load().mappo_gru_backward(_ptr(params), C.byref(desc), _ptr(scratch), _ptr(masks), _ptr(rows, torch.int32, allow_none=True),
+                                        int(L), int(Nc), int(head), n(avail), n(actions), n(old_logp), n(adv), _ptr(active), n(v_old),
+                                        n(returns), n(vn_state), _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(dxT), _ptr(dgiT),
+                                        _ptr(dghnT), _ptr(slabs), int(slab_stride), int(slab_col0), _ptr(partials, torch.float64),
+                                        _stream())
+    _lib.check(rc, "mappo_gru_backward")
+
+
+def gru_wgrad_slabs(L, Nc):
+    return int(_lib.load().mappo_gru_wgrad_slabs(int(L), int(Nc)))
+
+
+def gru_wgrad(desc, featT, scratch, dgiT, dghnT, L, Nc, slabs, slab_stride, slab_col0):
+    rc = _lib.load().mappo_gru_wgrad(C.byref(desc), _ptr(featT), _ptr(scratch), _ptr(dgiT), _ptr(dghnT), int(L), int(Nc), _ptr(slabs),
+                                     int(slab_stride), int(slab_col0), _stream())
+    _lib.check(rc, "mappo_gru_wgrad")
+
+
+def trunk_backward(params, desc, x, rows, B, dxT, slabs, slab_stride, slab_col0):
+    rc = _lib.load().mappo_trunk_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(B),
+                                          _ptr(dxT), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+    _lib.check(rc, "mappo_trunk_backward")
 
 
 # ---- K10 / K11 ------------------------------------------------------------------------------------

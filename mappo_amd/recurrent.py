@@ -1,12 +1,186 @@
-"""GRU (recurrent policy) path — `onpolicy/algorithms/utils/rnn.py:7-80` + the chunked generators.
+"""GRU (recurrent policy) path — `onpolicy/algorithms/utils/rnn.py:7-80`, the chunked / whole-episode generators
+(`shared_buffer.py:288-494`) and the recurrent branch of `R_MAPPO.train` (`r_mappo.py:194-200`).
 
-Built on the GRU kernels of mappo_amd/csrc/gru.hip (single-step cell for rollouts, L-step masked sequence
-with BPTT for training).  Until those entry points exist in libmappo_hip.so these functions refuse loudly."""
+A recurrent network is trunk -> GRU -> LayerNorm -> head.  Forward: mappo_mlp_features (trunk, feature-major
+[64][B]) + mappo_gru_forward.  Training, per network and minibatch of `mbs` chunks x L steps (time-major, the order
+of the reference's stacked chunks): features -> gru_forward (stores gates) -> gru_backward (reverse time, head +
+in-kernel PPO loss, d x) -> gru_wgrad -> trunk_backward, all writing gradient slabs over the joint flat layout.
+Row indices come from SharedReplayBuffer.recurrent_rows / naive_recurrent_rows (the reference's index arithmetic,
+including chunks that straddle two series when T % L != 0)."""
+import numpy as np
+import torch
+
+from mappo_amd import ops
+from mappo_amd.utils.util import to_device_f32
+
+H = 64
 
 
-def _missing(*_a, **_k):
-    raise NotImplementedError("recurrent (GRU) policies: the GRU kernels are not part of this build yet — "
-                              "use algorithm_name=mappo (MLP policy); there is no torch fallback")
+class _Scratch:
+    """Feature-major work arrays of one network pass, cached per (L, Nc)."""
+
+    def __init__(self):
+        self._c = {}
+
+    def get(self, device, L, Nc, training):
+        key = (L, Nc, training)
+        s = self._c.get(key)
+        if s is None:
+            B = L * Nc
+            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
+            s = dict(featT=f(H, B))
+            if training:
+                s.update(gates=f(ops.gru_scratch_floats(L, Nc)), dxT=f(H, B), dgiT=f(3 * H, B), dghnT=f(H, B))
+            self._c[key] = s
+        return s
 
 
-actor_step = actor_sequence_logits = critic_forward = train_recurrent = ppo_update_recurrent = _missing
+_scratch = _Scratch()
+
+
+def _seq_shape(n_rows, rnn_states):
+    Nc = rnn_states.shape[0]
+    assert n_rows % Nc == 0, "rows must be L * (number of rnn states)"
+    return n_rows // Nc, Nc
+
+
+# ---- forward entry points used by R_Actor / R_Critic --------------------------------------------------------------
+def actor_step(actor, obs, rnn_states, masks, avail, deterministic, actions_f, logp, counter=None):
+    """R_Actor.forward for a recurrent actor (r_actor_critic.py:43-70): one GRU step per row (rollout / act)."""
+    B = obs.shape[0]
+    L, Nc = _seq_shape(B, rnn_states)
+    if L != 1:
+        raise NotImplementedError("R_Actor.forward samples one step per row (the reference does the same: rnn.py:25-29)")
+    s = _scratch.get(actor.device_, 1, Nc, False)
+    ops.mlp_features(actor.flat, actor.desc, obs, None, B, s["featT"])
+    h_next = torch.empty(Nc, actor._recurrent_N, H, dtype=torch.float32, device=actor.device_)
+    if counter is None:
+        counter = actor._sample_counter
+        actor._sample_counter += 1
+    ops.gru_forward(actor.flat, actor.desc, s["featT"], rnn_states.reshape(Nc, H), None, masks.reshape(B), None, 1, Nc,
+                    h_last=h_next.view(Nc, H), head_mode=2, avail=avail, deterministic=deterministic, seed=actor._seed,
+                    counter=counter, counter_dev=actor._counter_dev, actions=actions_f, logp=logp)
+    return h_next
+
+
+def actor_sequence_logits(actor, obs, rnn_states, masks):
+    """Pre-mask logits for every row of a (L*Nc)-row time-major batch (evaluate_actions, r_actor_critic.py:72-107)."""
+    B = obs.shape[0]
+    L, Nc = _seq_shape(B, rnn_states)
+    s = _scratch.get(actor.device_, L, Nc, False)
+    ops.mlp_features(actor.flat, actor.desc, obs, None, B, s["featT"])
+    logits = torch.empty(B, actor.n_actions, dtype=torch.float32, device=actor.device_)
+    ops.gru_forward(actor.flat, actor.desc, s["featT"], rnn_states.reshape(Nc, H), None, masks.reshape(B), None, L, Nc,
+                    head_mode=1, out=logits)
+    return logits
+
+
+def critic_forward(critic, cent_obs, rnn_states, masks, values):
+    """R_Critic.forward (r_actor_critic.py:146-165): single step (rows == states) or L-step sequences."""
+    B = cent_obs.shape[0]
+    L, Nc = _seq_shape(B, rnn_states)
+    s = _scratch.get(critic.device_, L, Nc, False)
+    ops.mlp_features(critic.flat, critic.desc, cent_obs, None, B, s["featT"])
+    h_next = torch.empty(Nc, critic._recurrent_N, H, dtype=torch.float32, device=critic.device_)
+    ops.gru_forward(critic.flat, critic.desc, s["featT"], rnn_states.reshape(Nc, H), None, masks.reshape(B), None, L, Nc,
+                    h_last=h_next.view(Nc, H), head_mode=1, out=values.view(B, 1))
+    return h_next
+
+
+# ---- training -------------------------------------------------------------------------------------------------------
+def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
+    """One PPO update on `Nc` sequences of `L` steps (r_mappo.py:91-164 with the recurrent evaluate_actions)."""
+    pol = tr.policy
+    B = L * Nc
+    lib = ops._lib.load()
+    dev = tr.device
+    vn_state = tr.value_normalizer.state if tr._use_valuenorm else None
+    ops.minibatch_moments(src["returns"], src["active"], rows, B, tr._mb_moments,
+                          tr._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
+    if tr._dist is not None:
+        tr._dist.all_reduce_sum_(tr._mb_moments)
+    if tr._use_valuenorm:
+        ops.valuenorm_update(vn_state, tr._mb_moments, tr.value_normalizer.beta)
+    n_trunk, n_bwd, n_wg = ops.mlp_backward_slabs(B), ops.gru_backward_slabs(Nc), ops.gru_wgrad_slabs(L, Nc)
+    n_slabs = max(n_trunk, n_bwd, n_wg)
+    P = pol.n_flat
+    slabs = tr._buf("slabs_rec", (n_slabs, P), zero=True)      # rows a kernel never writes stay zero
+    if not update_actor and not tr._actor_slabs_clean:
+        slabs[:, :pol.seg_bounds[1]].zero_()
+    tr._actor_slabs_clean = not update_actor
+    pa = tr._buf("partials_a", (1024,), torch.float64, zero=True)
+    pc = tr._buf("partials_c", (1024,), torch.float64, zero=True)
+    s = _scratch.get(dev, L, Nc, True)
+    nets = []
+    if update_actor:
+        nets.append((pol.actor, src["obs"], src["h0_a"], 1, pa, 0))
+    nets.append((pol.critic, src["share_obs"], src["h0_c"], 2, pc, pol.seg_bounds[1]))
+    for net, x, h0, head, part, col0 in nets:
+        ops.mlp_features(net.flat, net.desc, x, rows, B, s["featT"])
+        ops.gru_forward(net.flat, net.desc, s["featT"], h0, h0_rows, src["masks"], rows, L, Nc, scratch=s["gates"], head_mode=0)
+        ops.gru_backward(net.flat, net.desc, s["gates"], src["masks"], rows, L, Nc, head,
+                         src["avail"] if head == 1 else None, src["actions"] if head == 1 else None,
+                         src["old_logp"] if head == 1 else None, src["adv"] if head == 1 else None, src["active"],
+                         src["v_old"] if head == 2 else None, src["returns"] if head == 2 else None,
+                         vn_state if head == 2 else None, tr._mb_moments, tr._cfg, s["dxT"], s["dgiT"], s["dghnT"], slabs, P, col0, part)
+        ops.gru_wgrad(net.desc, s["featT"], s["gates"], s["dgiT"], s["dghnT"], L, Nc, slabs, P, col0)
+        ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
+    ops.update_stats(pa if update_actor else None, n_bwd, pc, n_bwd, tr._mb_moments, tr._cfg, tr._stats)
+    ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
+    if tr._dist is not None:
+        tr._dist.all_reduce_sum_(pol.flat_grad)
+    if update_actor != tr._actor_enabled:
+        pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
+        tr._actor_enabled = update_actor
+    ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper, pol.opt_step,
+                  pol.grad_norms, pol.opt_workspace)
+    tr._acc[:4].add_(tr._stats[:4])
+    tr._acc[4:].add_(pol.grad_norms)
+
+
+def _buffer_sources(tr, buffer, adv):
+    T = buffer.episode_length
+    S = T * buffer.n_rollout_threads * buffer.num_agents
+    flat = lambda a: a[:T].view(S, -1)
+    return dict(obs=flat(buffer.obs), share_obs=flat(buffer.share_obs),
+                avail=flat(buffer.available_actions) if buffer.available_actions is not None else None,
+                actions=buffer.actions.view(S), old_logp=buffer.action_log_probs.view(S), adv=adv,
+                active=buffer.active_masks[:T].view(S), v_old=buffer.value_preds[:T].view(S), returns=buffer.returns[:T].view(S),
+                masks=buffer.masks[:T].view(S), h0_a=buffer.rnn_states[:T].view(S, H), h0_c=buffer.rnn_states_critic[:T].view(S, H))
+
+
+def train_recurrent(tr, buffer, update_actor=True):
+    """R_MAPPO.train for use_recurrent_policy (chunks of data_chunk_length) / use_naive_recurrent_policy (episodes)."""
+    if buffer.recurrent_N != 1:
+        raise NotImplementedError("recurrent_N != 1")
+    adv = tr.compute_advantages(buffer)
+    src = _buffer_sources(tr, buffer, adv)
+    T = buffer.episode_length
+    tr._acc.zero_()
+    for _ in range(tr.ppo_epoch):
+        if tr._use_recurrent_policy:
+            L = tr.data_chunk_length
+            batches = buffer.recurrent_rows(tr.num_mini_batch, L)
+        else:
+            L = T
+            batches = buffer.naive_recurrent_rows(tr.num_mini_batch)
+        for rows, h0_rows in batches:
+            _update_recurrent(tr, src, rows, h0_rows, L, h0_rows.numel(), update_actor)
+    return tr._finish_train_info()
+
+
+def ppo_update_recurrent(tr, sample, update_actor=True):
+    """R_MAPPO.ppo_update with an explicit (already gathered, time-major) recurrent sample tuple."""
+    (share_obs, obs, rnn_a, rnn_c, actions, v_old, ret, masks, active, old_logp, adv, avail) = sample
+    d = lambda x: to_device_f32(x, tr.device)
+    rnn_a, rnn_c = d(rnn_a), d(rnn_c)
+    Nc = rnn_a.shape[0]
+    B = (obs.shape[0] if torch.is_tensor(obs) else np.shape(obs)[0])
+    L = B // Nc
+    src = dict(obs=d(obs), share_obs=d(share_obs), avail=d(avail) if avail is not None else None, actions=d(actions).view(B),
+               old_logp=d(old_logp).view(B), adv=d(adv).view(B), active=d(active).view(B), v_old=d(v_old).view(B),
+               returns=d(ret).view(B), masks=d(masks).view(B), h0_a=rnn_a.reshape(Nc, H), h0_c=rnn_c.reshape(Nc, H))
+    tr._acc.zero_()
+    _update_recurrent(tr, src, None, None, L, Nc, update_actor)
+    a = tr._acc.cpu().numpy()
+    return a[0], a[5], a[1], a[2], a[4], a[3]

@@ -1,0 +1,141 @@
+"""GPU parity tests of the recurrent (GRU) path against the reference's golden vectors and the oracle:
+single-step get_actions / get_values, L-step masked sequences (rnn.py:30-77), the recurrent ppo_update with
+per-parameter gradients, and R_MAPPO.train with recurrent_generator's chunking (T % L == 0 and != 0)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, sub
+from oracle import mappo_oracle as O
+from test_gpu_e2e import M, make_args, load_policy, set_vn, fill_buffer, close, TUPLE, BUF_NAMES   # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+def close_rel_max(a, b, tol, msg=""):
+    a = a.detach().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+    assert err <= tol, f"{msg}: max err / max|ref| = {err:.3e} > {tol}"
+
+
+@pytest.mark.parametrize("case", [2, 3])
+def test_gru_forward_golden(M, case):
+    g = golden("forward")
+    d = sub(g, f"c{case}")
+    relu, rec, D, S, A, B, H = [int(x) for x in d["spec"]]
+    assert rec
+    a = make_args(M, use_ReLU=bool(relu), use_recurrent_policy=True)
+    pol = M.R_MAPPOPolicy(a, [D], [S], M.Discrete(A))
+    pol.actor.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sub(g, f"c{case}/actor").items()})
+    pol.critic.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sub(g, f"c{case}/critic").items()})
+    for tag in ("avail", "noavail"):
+        av = d["avail"] if tag == "avail" else None
+        v, act, lp, ra, rc = pol.get_actions(d["share_obs"], d["obs"], d["rnn_a"], d["rnn_c"], d["masks"], av, deterministic=True)
+        np.testing.assert_array_equal(act.cpu().numpy(), d[f"{tag}/actions"])
+        close(lp, d[f"{tag}/logp"], 1e-5, 2e-6); close(v, d[f"{tag}/values"], 1e-5, 2e-6)
+        close(ra, d[f"{tag}/rnn_a"], 1e-5, 2e-6); close(rc, d[f"{tag}/rnn_c"], 1e-5, 2e-6)
+        close(pol.get_values(d["share_obs"], d["rnn_c"], d["masks"]), d[f"{tag}/get_values"], 1e-5, 2e-6)
+        ev, elp, eent = pol.evaluate_actions(d["share_obs"], d["obs"], d["rnn_a"], d["rnn_c"], d[f"{tag}/actions"].astype(np.float32),
+                                             d["masks"], av, d[f"{tag}/active"])
+        close(ev, d[f"{tag}/eval_values"], 1e-5, 2e-6); close(elp, d[f"{tag}/eval_logp"], 1e-5, 2e-6)
+        close(eent, d[f"{tag}/eval_entropy"], 1e-5, 1e-6)
+    # L-step chunk with zero masks inside (the reference's segment loop == per-step h*mask)
+    ev, elp, eent = pol.evaluate_actions(d["seq/share_obs"], d["seq/obs"], d["seq/h0a"], d["seq/h0c"], d["seq/actions"], d["seq/masks"],
+                                         d["seq/avail"], d["seq/active"])
+    close(ev, d["seq/values"], 1e-5, 3e-6); close(elp, d["seq/logp"], 1e-5, 3e-6); close(eent, d["seq/entropy"], 1e-5, 1e-6)
+
+
+def test_ppo_update_recurrent_golden(M):
+    """golden ppo_update c9: recurrent_generator sample (L=10 chunks of T=20 x N=2 x M=3), ReLU, H=64."""
+    g = golden("ppo_update")
+    c = 9
+    d = sub(g, f"c{c}")
+    T, N, Ma, D, S, A, H = [int(x) for x in d["dims"]]
+    fl = dict(zip([str(x) for x in d["flag_names"]], [bool(x) for x in d["flags"]]))
+    assert fl["use_recurrent_policy"] and H == 64
+    hy = d["hyper"]
+    a = make_args(M, episode_length=T, n_rollout_threads=N, lr=float(hy[5]), critic_lr=float(hy[6]), use_recurrent_policy=True,
+                  data_chunk_length=int(hy[9]))
+    pol = load_policy(M, a, g, f"c{c}", D, S, A)
+    tr = M.R_MAPPO(a, pol)
+    set_vn(tr, d["vn0"])
+    sample = tuple(d[f"sample/{nm}"] for nm in TUPLE)
+    out = tr.ppo_update(sample)
+    close(np.array(out, dtype=np.float64), d["r0/stats"], 2e-5, 1e-7, "stats")
+    # raw (pre-clip == post-clip here: max_grad_norm 10) gradients, parameter by parameter
+    for tag, net, seg in (("actor", pol.actor, 0), ("critic", pol.critic, 1)):
+        lo = pol.seg_bounds[seg]
+        for key, off, shape in net.layout:
+            n = int(np.prod(shape))
+            close_rel_max(pol.flat_grad[lo + off: lo + off + n].view(shape), d[f"r0/{tag}_grad/{key}"], 2e-4, f"{tag} grad {key}")
+        ref_sd = sub(g, f"c{c}/r0/{tag}")
+        for k, v in net.state_dict().items():
+            close(v, ref_sd[k], 1e-5, 4e-6, f"{tag} {k}")
+    close(tr.value_normalizer.state, d["r0/vn"], 2e-6, 1e-9)
+
+
+def test_train_recurrent_golden(M):
+    """golden train c1: R_MAPPO.train with recurrent_generator (T=20, L=10, num_mini_batch=1, 2 epochs, CPU permutation)."""
+    g = golden("train")
+    d = sub(g, "c1")
+    T, N, Ma, D, S, A, H, nmb, rec, epochs, L = [int(x) for x in d["dims"]]
+    assert rec
+    a = make_args(M, episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=epochs, num_mini_batch=nmb,
+                  use_recurrent_policy=True, data_chunk_length=L, perm_device="cpu")
+    pol = load_policy(M, a, g, "c1", D, S, A)
+    tr = M.R_MAPPO(a, pol)
+    buf = M.SharedReplayBuffer(a, Ma, [D], [S], M.Discrete(A))
+    fill_buffer(buf, d)
+    torch.manual_seed(3000 + 1)
+    info = tr.train(buf)
+    ref = dict(zip([str(k) for k in d["info_keys"]], d["info"]))
+    for k, v in info.items():
+        close(v, ref[k], 1e-4, 1e-7, k)
+    for tag, net in (("actor1", pol.actor), ("critic1", pol.critic)):
+        ref_sd = sub(g, f"c1/{tag}")
+        for k, v in net.state_dict().items():
+            close(v, ref_sd[k], 1e-4, 6e-6, f"{tag} {k}")
+    close(tr.value_normalizer.state, d["vn1"], 2e-6, 1e-9)
+
+
+def test_recurrent_train_straddling_chunks_vs_oracle(M):
+    """T % L != 0 (MPE rmappo: T=25, L=10): chunks straddle two series and the tail is dropped;
+    same buffer + weights through the oracle's recurrent train."""
+    T, N, Ma, D, A, L = 25, 4, 3, 18, 5, 10
+    a = make_args(M, episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=2, num_mini_batch=2,
+                  use_recurrent_policy=True, data_chunk_length=L, perm_device="cpu")
+    torch.manual_seed(5)
+    pol = M.R_MAPPOPolicy(a, [D], [D * Ma], M.Discrete(A))
+    tr = M.R_MAPPO(a, pol)
+    buf = M.SharedReplayBuffer(a, Ma, [D], [D * Ma], M.Discrete(A))
+    rng = np.random.default_rng(3)
+    f = np.float32
+    for n in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "rewards"):
+        arr = getattr(buf, n); arr.copy_(torch.from_numpy(rng.standard_normal(tuple(arr.shape)).astype(f)))
+    buf.value_preds.copy_(torch.from_numpy((rng.standard_normal(tuple(buf.value_preds.shape)) * 0.3).astype(f)))
+    buf.returns.copy_(torch.from_numpy((rng.standard_normal(tuple(buf.returns.shape)) * 2).astype(f)))
+    buf.actions.copy_(torch.from_numpy(rng.integers(0, A, tuple(buf.actions.shape)).astype(f)))
+    buf.action_log_probs.copy_(torch.from_numpy((-np.abs(rng.standard_normal(tuple(buf.actions.shape))) - 1).astype(f)))
+    buf.masks.copy_(torch.from_numpy((rng.random(tuple(buf.masks.shape)) > 0.15).astype(f)))
+    buf.active_masks.copy_(torch.from_numpy((rng.random(tuple(buf.masks.shape)) > 0.2).astype(f)))
+    oa = O.default_args(episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=2, num_mini_batch=2,
+                        use_recurrent_policy=True, data_chunk_length=L)
+    opol = O.PolicyRef(oa, D, D * Ma, A)
+    opol.actor.load_state_dict({k: v.cpu() for k, v in pol.actor.state_dict().items()})
+    opol.critic.load_state_dict({k: v.cpu() for k, v in pol.critic.state_dict().items()})
+    ob = O.BufferRef(oa, Ma, D, D * Ma, A)
+    for n in BUF_NAMES:
+        getattr(ob, n)[...] = getattr(buf, n).cpu().numpy()
+    ovn = O.ValueNormRef()
+    torch.manual_seed(11)
+    perms = [torch.randperm((T * N * Ma) // L).numpy() for _ in range(2)]
+    oinfo = O.train_ref(oa, opol, ovn, ob, perms=perms)
+    torch.manual_seed(11)
+    info = tr.train(buf)
+    for k in oinfo:
+        close(info[k], oinfo[k], 1e-4, 1e-6, k)
+    for k, v in pol.actor.state_dict().items():
+        close(v, opol.actor.state_dict()[k].numpy(), 1e-4, 6e-6, k)
+    for k, v in pol.critic.state_dict().items():
+        close(v, opol.critic.state_dict()[k].numpy(), 1e-4, 6e-6, k)

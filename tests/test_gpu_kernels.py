@@ -476,7 +476,7 @@ def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, wit
     ops.actor_update(pa, da, g["obs"], d_rows, B, g["avail"], g["actions"], g["old"], g["adv"], g["active"], mom, cfg, slabs, P, 0, part_a)
     ops.critic_update(pc, dc, g["sobs"], d_rows, B, g["vold"], g["ret"], g["active"], g["vn"], mom, cfg, slabs, P, col_c, part_c)
     stats_f = torch.zeros(6, dtype=torch.float64, device="cuda")
-    ops.update_stats(part_a, part_c, B, mom, cfg, stats_f)
+    ops.update_stats(part_a, ns, part_c, ns, mom, cfg, stats_f)
     grad_f = torch.zeros(P, device="cuda")
     ops.slab_reduce(slabs, ns, P, P, grad_f)
     # (2) unfused
