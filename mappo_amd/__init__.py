@@ -22,6 +22,7 @@ _ALIASES = {
     "onpolicy.algorithms.r_mappo.algorithm.r_actor_critic": "mappo_amd.algorithms.r_mappo.algorithm.r_actor_critic",
     "onpolicy.runner.shared.base_runner": "mappo_amd.runner.shared.base_runner",
     "onpolicy.runner.shared.mpe_runner": "mappo_amd.runner.shared.mpe_runner",
+    "onpolicy.runner.shared.smac_runner": "mappo_amd.runner.shared.smac_runner",
 }
 
 

@@ -41,3 +41,50 @@ class SyntheticMPEEnv:
 
     def close(self):
         pass
+
+
+class SyntheticSMACEnv:
+    """SMAC-shaped synthetic vec-env: `reset() -> (obs, share_obs, avail)`,
+    `step(actions [N, M, 1]) -> (obs, share_obs, rewards, dones [N, M], bad_transition [N, M] bool, avail)`.
+    Agents die with probability `p_death` per step, an env terminates with probability `p_term` per step (all its
+    agents report done; it restarts alive), action 0 is always available and the others with probability 0.7;
+    `bad_transition` is always False.  Everything stays on the device."""
+    graph_safe = True
+
+    def __init__(self, n_rollout_threads, num_agents=3, obs_dim=30, share_dim=48, n_actions=9, p_death=0.01, p_term=1.0 / 60,
+                 seed=1, device="cuda"):
+        self.N, self.M, self.D, self.S, self.A = n_rollout_threads, num_agents, obs_dim, share_dim, n_actions
+        self.p_death, self.p_term = p_death, p_term
+        self.device = torch.device(device)
+        self.observation_space = [[obs_dim] for _ in range(num_agents)]
+        self.share_observation_space = [[share_dim] for _ in range(num_agents)]
+        self.action_space = [Discrete(n_actions) for _ in range(num_agents)]
+        self.dead = torch.zeros(self.N, self.M, dtype=torch.bool, device=self.device)
+        with torch.cuda.device(self.device):
+            torch.cuda.manual_seed(seed)
+
+    def _draw(self):
+        N, M, dev = self.N, self.M, self.device
+        obs = torch.randn(N, M, self.D, device=dev)
+        share = torch.randn(N, M, self.S, device=dev)
+        avail = (torch.rand(N, M, self.A, device=dev) < 0.7).to(torch.float32)
+        avail[:, :, 0] = 1.0
+        return obs, share, avail
+
+    def reset(self):
+        self.dead.zero_()
+        return self._draw()
+
+    def step(self, actions=None):
+        N, M, dev = self.N, self.M, self.device
+        obs, share, avail = self._draw()
+        rewards = torch.randn(N, 1, 1, device=dev).expand(N, M, 1)
+        self.dead |= torch.rand(N, M, device=dev) < self.p_death
+        term = torch.rand(N, device=dev) < self.p_term
+        dones = self.dead | term.view(N, 1)
+        self.dead &= ~term.view(N, 1)                       # a terminated env restarts with every agent alive
+        bad = torch.zeros(N, M, dtype=torch.bool, device=dev)
+        return obs, share, rewards, dones, bad, avail
+
+    def close(self):
+        pass

@@ -1,0 +1,113 @@
+"""SMACRunner — API of `onpolicy/runner/shared/smac_runner.py:11-214` (training loop, warmup, collect, insert,
+log_train, eval).  SMAC-style vec-env contract (env_wrappers.py:363-379): `reset() -> (obs, share_obs, avail)`,
+`step(actions [N, M, 1]) -> (obs, share_obs, rewards, dones [N, M], infos, avail)` with
+`infos[i][m]['bad_transition']`.  The rollout step is fused like MPERunner's: the policy kernels write actions /
+log-probs / values into buffer slot `step`, `insert` stores what the environment returned and derives masks,
+active_masks and bad_masks exactly as smac_runner.py:129-151."""
+import time
+from functools import reduce
+
+import numpy as np
+import torch
+
+from .base_runner import Runner, _t2n
+
+
+class SMACRunner(Runner):
+    def __init__(self, config):
+        super(SMACRunner, self).__init__(config)
+
+    def run(self):
+        self.warmup()
+        start = time.time()
+        episodes = int(self.num_env_steps) // self.episode_length // self.n_rollout_threads
+        last_battles_game = np.zeros(self.n_rollout_threads, dtype=np.float32)
+        last_battles_won = np.zeros(self.n_rollout_threads, dtype=np.float32)
+        for episode in range(episodes):
+            train_infos, infos = self.run_episode(episode, episodes)
+            total_num_steps = (episode + 1) * self.episode_length * self.n_rollout_threads
+            if episode % self.save_interval == 0 or episode == episodes - 1:
+                self.save()
+            if episode % self.log_interval == 0:
+                end = time.time()
+                print("\n Map {} Algo {} Exp {} updates {}/{} episodes, total num timesteps {}/{}, FPS {}.\n".format(
+                    getattr(self.all_args, "map_name", "synthetic"), self.algorithm_name, self.experiment_name, episode, episodes,
+                    total_num_steps, self.num_env_steps, int(total_num_steps / (end - start))))
+                if self.env_name == "StarCraft2" and infos is not None:
+                    battles_won, battles_game, incre_won, incre_game = [], [], [], []
+                    for i, info in enumerate(infos):
+                        if "battles_won" in info[0].keys():
+                            battles_won.append(info[0]["battles_won"]); incre_won.append(info[0]["battles_won"] - last_battles_won[i])
+                        if "battles_game" in info[0].keys():
+                            battles_game.append(info[0]["battles_game"]); incre_game.append(info[0]["battles_game"] - last_battles_game[i])
+                    incre_win_rate = np.sum(incre_won) / np.sum(incre_game) if np.sum(incre_game) > 0 else 0.0
+                    print("incre win rate is {}.".format(incre_win_rate))
+                    self.log_env({"incre_win_rate": [incre_win_rate]}, total_num_steps)
+                    if battles_game:
+                        last_battles_game, last_battles_won = battles_game, battles_won
+                shape = list(self.buffer.active_masks.shape)
+                train_infos["dead_ratio"] = 1 - float(self.buffer.active_masks.sum().item()) / reduce(lambda x, y: x * y, shape)
+                self.log_train(train_infos, total_num_steps)
+            if episode % self.eval_interval == 0 and self.use_eval:
+                self.eval(total_num_steps)
+
+    def run_episode(self, episode=0, episodes=1):
+        if self.use_linear_lr_decay:
+            self.trainer.policy.lr_decay(episode, episodes)
+        infos = None
+        for step in range(self.episode_length):
+            values, actions, action_log_probs, rnn_states, rnn_states_critic = self.collect(step)
+            obs, share_obs, rewards, dones, infos, available_actions = self.envs.step(actions)
+            self.insert((obs, share_obs, rewards, dones, infos, available_actions, values, actions, action_log_probs,
+                         rnn_states, rnn_states_critic))
+        self.compute()
+        return self.train(), infos
+
+    # smac_runner.py:98-108
+    def warmup(self):
+        obs, share_obs, available_actions = self.envs.reset()
+        if not self.use_centralized_V:
+            share_obs = obs
+        b = self.buffer
+        b._put(b.share_obs[0], share_obs)
+        b._put(b.obs[0], obs)
+        b._put(b.available_actions[0], available_actions)
+
+    # smac_runner.py:110-127
+    @torch.no_grad()
+    def collect(self, step):
+        self.trainer.prep_rollout()
+        b = self.buffer
+        actions, rnn_states, rnn_states_critic = self.trainer.policy.collect_into(b, step, use_available_actions=True)
+        if getattr(self.envs, "needs_host_actions", False):
+            actions = _t2n(actions)
+        return b.value_preds[step], actions, b.action_log_probs[step], rnn_states, rnn_states_critic
+
+    # smac_runner.py:129-151
+    def insert(self, data):
+        obs, share_obs, rewards, dones, infos, available_actions, values, actions, action_log_probs, rnn_states, rnn_states_critic = data
+        b = self.buffer
+        dev, N, Ma = b.device, b.n_rollout_threads, b.num_agents
+        dones_t = torch.as_tensor(dones).to(dev).view(N, Ma)
+        dones_env = dones_t.all(dim=1)                                                       # :132
+        keep_env = (~dones_env).to(torch.float32)
+        masks = keep_env.view(N, 1, 1).expand(N, Ma, 1)                                      # :137-138
+        active_masks = torch.where(dones_env.view(N, 1), torch.ones((), device=dev),
+                                   (~dones_t).to(torch.float32)).view(N, Ma, 1)              # :140-142
+        if isinstance(infos, torch.Tensor):                                                  # device env: bad_transition [N, M] bool
+            bad_masks = (~infos.to(dev)).to(torch.float32).view(N, Ma, 1)
+        else:                                                                                # :144
+            bad_masks = torch.tensor([[[0.0] if info[agent_id]["bad_transition"] else [1.0] for agent_id in range(Ma)]
+                                      for info in infos], dtype=torch.float32, device=dev)
+        rnn_a = rnn_c = None
+        if self.trainer._use_recurrent_policy or self.trainer._use_naive_recurrent:
+            k = keep_env.view(N, 1, 1, 1)
+            rnn_a = rnn_states.view(N, Ma, b.recurrent_N, -1) * k                           # :134-135
+            rnn_c = rnn_states_critic.view(N, Ma, b.recurrent_N, -1) * k
+        if not self.use_centralized_V:
+            share_obs = obs
+        b.insert_env(share_obs, obs, rewards, masks, rnn_a, rnn_c, bad_masks, active_masks, available_actions)
+
+    def log_train(self, train_infos, total_num_steps):
+        train_infos["average_step_rewards"] = float(self.buffer.rewards.mean().item())       # :154
+        super().log_train(train_infos, total_num_steps)

@@ -139,3 +139,83 @@ def test_recurrent_train_straddling_chunks_vs_oracle(M):
         close(v, opol.actor.state_dict()[k].numpy(), 1e-4, 6e-6, k)
     for k, v in pol.critic.state_dict().items():
         close(v, opol.critic.state_dict()[k].numpy(), 1e-4, 6e-6, k)
+
+
+@pytest.mark.parametrize("runner_kind", ["mpe", "smac"])
+def test_recurrent_runner_iteration_vs_oracle(M, runner_kind):
+    """rmappo end to end on the GPU: rollout with the GRU act/value kernels through MPERunner / SMACRunner (availability
+    masks, agent deaths, env terminations), then bootstrap + GAE + recurrent train against the oracle on the same
+    buffer and weights.  Rollout outputs are re-derived step by step by the oracle from the stored rnn states."""
+    from mappo_amd.runner.shared.smac_runner import SMACRunner
+    from mappo_amd.envs.synthetic import SyntheticSMACEnv
+    T, N, Ma, L = 20, 6, 3, 10
+    if runner_kind == "mpe":
+        D, S, A = 18, 54, 5
+        env = M.SyntheticMPEEnv(N, Ma, D, A, T, seed=2)
+        R = M.MPERunner
+    else:
+        D, S, A = 30, 48, 9
+        env = SyntheticSMACEnv(N, Ma, D, S, A, p_death=0.05, p_term=0.1, seed=2)
+        R = SMACRunner
+    a = make_args(M, episode_length=T, n_rollout_threads=N, ppo_epoch=2, num_mini_batch=1, lr=7e-4, critic_lr=7e-4, seed=1,
+                  env_name="MPE", use_recurrent_policy=True, algorithm_name="rmappo", data_chunk_length=L, perm_device="cpu",
+                  use_hip_graph=False)
+    torch.manual_seed(1)
+    runner = R(dict(all_args=a, envs=env, eval_envs=None, num_agents=Ma, device=torch.device("cuda"), run_dir=None))
+    oa = O.default_args(episode_length=T, n_rollout_threads=N, ppo_epoch=2, lr=7e-4, critic_lr=7e-4, use_recurrent_policy=True,
+                        data_chunk_length=L)
+    opol = O.PolicyRef(oa, D, S, A)
+    opol.actor.load_state_dict({k: v.cpu() for k, v in runner.policy.actor.state_dict().items()})
+    opol.critic.load_state_dict({k: v.cpu() for k, v in runner.policy.critic.state_dict().items()})
+    runner.warmup()
+    for step in range(T):
+        out = runner.collect(step)
+        if runner_kind == "mpe":
+            values, actions, logp, rs, rc, actions_env = out
+            obs, rewards, dones, infos = env.step(actions_env)
+            runner.insert((obs, rewards, dones, infos, values, actions, logp, rs, rc))
+        else:
+            values, actions, logp, rs, rc = out
+            obs, share_obs, rewards, dones, infos, avail = env.step(actions)
+            runner.insert((obs, share_obs, rewards, dones, infos, avail, values, actions, logp, rs, rc))
+    b = runner.buffer
+    Rr = N * Ma
+    t_ = lambda x: x.cpu()
+    with torch.no_grad():
+        for step in (0, 7, T - 1):
+            av = t_(b.available_actions[step]).reshape(Rr, A) if runner_kind == "smac" else None
+            feats, ra = opol.actor.features(t_(b.obs[step]).reshape(Rr, D), t_(b.rnn_states[step]).reshape(Rr, 1, 64), t_(b.masks[step]).reshape(Rr, 1))
+            z = opol.actor.act.logits(feats, av)
+            lp, _, _ = opol.actor.act.logp_entropy(z, t_(b.actions[step]).reshape(Rr, 1))
+            v, rcr = opol.critic(t_(b.share_obs[step]).reshape(Rr, S), t_(b.rnn_states_critic[step]).reshape(Rr, 1, 64), t_(b.masks[step]).reshape(Rr, 1))
+            close(b.action_log_probs[step].reshape(Rr, 1), lp.numpy(), 1e-5, 3e-6, f"logp step {step}")
+            close(b.value_preds[step].reshape(Rr, 1), v.numpy(), 1e-5, 3e-6, f"value step {step}")
+            keep = t_(b.masks[step + 1]).reshape(Rr, 1, 1)                     # insert zeroes the states of finished envs
+            close(b.rnn_states[step + 1].reshape(Rr, 1, 64), (ra * keep).numpy(), 1e-5, 3e-6, f"rnn_a step {step}")
+            close(b.rnn_states_critic[step + 1].reshape(Rr, 1, 64), (rcr * keep).numpy(), 1e-5, 3e-6, f"rnn_c step {step}")
+    if runner_kind == "smac":
+        assert float(b.active_masks.min()) == 0.0 and float(b.masks.min()) == 0.0       # deaths and terminations occurred
+        picked = torch.gather(b.available_actions[:T], -1, b.actions.long())
+        assert float(picked.min()) == 1.0                                              # only available actions were taken
+    ob = O.BufferRef(oa, Ma, D, S, A)
+    for n in BUF_NAMES:
+        if n != "returns":
+            getattr(ob, n)[...] = getattr(b, n).cpu().numpy()
+    ovn = O.ValueNormRef()
+    with torch.no_grad():
+        nv, _ = opol.critic(torch.from_numpy(np.concatenate(ob.share_obs[-1])), torch.from_numpy(np.concatenate(ob.rnn_states_critic[-1])),
+                            torch.from_numpy(np.concatenate(ob.masks[-1])))
+    ob.compute_returns(np.array(np.split(nv.numpy(), N)), ovn)
+    runner.compute()
+    close(b.returns[:T], ob.returns[:T], 1e-5, 3e-6)
+    torch.manual_seed(21)
+    perms = [torch.randperm((T * N * Ma) // L).numpy() for _ in range(2)]
+    oinfo = O.train_ref(oa, opol, ovn, ob, perms=perms)
+    torch.manual_seed(21)
+    info = runner.train()
+    for k in oinfo:
+        close(info[k], oinfo[k], 1e-4, 1e-6, k)
+    for k, vv in runner.policy.actor.state_dict().items():
+        close(vv, opol.actor.state_dict()[k].numpy(), 1e-4, 6e-6, k)
+    for k, vv in runner.policy.critic.state_dict().items():
+        close(vv, opol.critic.state_dict()[k].numpy(), 1e-4, 6e-6, k)
