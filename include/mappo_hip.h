@@ -33,6 +33,7 @@ typedef void *mappo_stream_t; /* hipStream_t */
 #define MAPPO_ENOTIMPL (-3)  /* valid in the reference but not built here (e.g. popart) */
 
 #define MAPPO_HIDDEN 64      /* hidden_size the MFMA kernels are tiled for (config.py:199 default) */
+#define MAPPO_MAX_IN_DIM 512 /* obs / share_obs width */
 #define MAPPO_MAX_ACTIONS 32 /* Discrete(n) with n <= 32 */
 #define MAPPO_MAX_LAYER_N 2
 
@@ -136,7 +137,17 @@ int mappo_actor_act(const float *params, const mappo_net_desc *desc /*host*/, co
 int32_t mappo_mlp_backward_slabs(int64_t B); /* number of slabs the launch below will write */
 int mappo_mlp_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x,
                        const int32_t *rows, int64_t B, const float *dout /*[B][out_dim]*/,
-                       float *slabs, int64_t slab_stride, int64_t slab_col0, mappo_stream_t stream);
+                       float *slabs, int64_t slab_stride, int64_t slab_col0,
+                       float *wide_ws /*in_dim > 64: mappo_wide_workspace_floats(B) floats, else NULL*/,
+                       mappo_stream_t stream);
+/* Wide observations (64 < in_dim <= 512): the update / backward kernels run layer 1 K-chunked and leave d z1 plus the
+ * per-row LayerNorm statistics in `wide_ws`; mappo_wide_l1_backward then produces the W1 and feature-norm gradient
+ * columns (one slab row per workgroup of its grid.x, mappo_wide_l1_slabs(B) rows). */
+int64_t mappo_wide_workspace_floats(int64_t B);
+int32_t mappo_wide_l1_slabs(int64_t B);
+int mappo_wide_l1_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x, const int32_t *rows,
+                           int64_t B, const float *wide_ws, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                           mappo_stream_t stream);
 
 /* ---- fused update kernels (K7 + K5 + K7-backward in ONE launch per network; r_mappo.py:91-164) --------------
  * The forward of a 32-sample tile, the loss gradient at the head and the backward pass run back to back in the
@@ -150,12 +161,14 @@ int mappo_actor_update(const float *params, const mappo_net_desc *desc /*host*/,
                        const int32_t *rows, int64_t B, const float *avail /*or NULL*/, const float *actions,
                        const float *old_logp, const float *adv, const float *active,
                        const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
-                       int64_t slab_stride, int64_t slab_col0, double *partials, mappo_stream_t stream);
+                       int64_t slab_stride, int64_t slab_col0, double *partials, float *wide_ws /*or NULL*/,
+                       mappo_stream_t stream);
 int mappo_critic_update(const float *params, const mappo_net_desc *desc /*host*/, const float *share_obs,
                         const int32_t *rows, int64_t B, const float *v_old, const float *returns,
                         const float *active, const float *vn_state /*[3] after update, or NULL*/,
                         const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
-                        int64_t slab_stride, int64_t slab_col0, double *partials, mappo_stream_t stream);
+                        int64_t slab_stride, int64_t slab_col0, double *partials, float *wide_ws /*or NULL*/,
+                        mappo_stream_t stream);
 int mappo_update_stats(const double *actor_partials, int32_t n_actor /*workgroups that wrote them*/,
                        const double *critic_partials, int32_t n_critic, const double *mb_moments,
                        const mappo_ppo_cfg *cfg /*host*/, double *stats /*[6]*/, mappo_stream_t stream);
@@ -195,7 +208,7 @@ int mappo_gru_wgrad(const mappo_net_desc *desc /*host*/, const float *featT, con
                     mappo_stream_t stream);
 int mappo_trunk_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x, const int32_t *rows,
                          int64_t B, const float *dxT /*[64][B]*/, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                         mappo_stream_t stream);
+                         float *wide_ws /*or NULL*/, mappo_stream_t stream);
 
 /* ---- K10/K11: slab reduction, global-norm clip, Adam (r_mappo.py:143-148,157-162; torch Adam) -------
  * The flat gradient covers `n_seg` parameter segments (actor, critic); norms/clip/lr are per segment.

@@ -29,8 +29,11 @@
 //   under the current tile's MFMA chains, and every workgroup writes ONE partial-gradient slab, summed by
 //   mappo_slab_reduce (deterministic, no float atomics).
 //
-// Limits of this build: hidden == 64, out_dim <= 32, layer_N <= 2, in_dim <= 64 (the K-chunked layer-1 path
-// for wider observations is a separate kernel).
+// Wide observations (in_dim > 64, up to 512: BASELINE configs 4-5) use the XW == 2 instantiations: layer 1 is
+// K-chunked (the workgroup streams 64-column chunks of W1 through LDS, each wave re-normalises its rows chunk by
+// chunk), and its weight / feature-norm gradients come from wide_l1_bwd_kernel, which owns one K-chunk per
+// workgroup and sweeps the row tiles (dz1 goes through a feature-major HBM scratch).
+// Limits of this build: hidden == 64, out_dim <= 32, layer_N <= 2, in_dim <= 512.
 #include "mlp_core.h"
 
 extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
@@ -46,17 +49,20 @@ struct LdsMap {
   int w1, w2[MAPPO_MAX_LAYER_N], wh;
   int fn_w, fn_b, b1, ln1_w, ln1_b, b2[MAPPO_MAX_LAYER_N], ln2_w[MAPPO_MAX_LAYER_N], ln2_b[MAPPO_MAX_LAYER_N], bh;
   int tiles, x_rows, wave_stride, total;
+  int fn_size;       // floats reserved per feature-norm vector (64, or in_dim rounded up to 64 for wide inputs)
 };
 
 
 __host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves) {
   LdsMap m;
   int p = 0;
-  const int Dp = (d.in_dim + 1) & ~1;
+  const bool xw = d.in_dim > MAXD;
+  const int Dp = xw ? MAXD : ((d.in_dim + 1) & ~1);          // wide inputs: one 64-column chunk of W1 / of the rows at a time
+  m.fn_size = xw ? ((d.in_dim + 63) / 64) * 64 : MAXD;
   m.w1 = p; p = al4(p + Dp * WP);
   for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) { m.w2[l] = p; if (l < d.layer_N) p = al4(p + HID * WP); }
   m.wh = p; p = al4(p + HID * HP);
-  m.fn_w = p; p += MAXD; m.fn_b = p; p += MAXD;
+  m.fn_w = p; p += m.fn_size; m.fn_b = p; p += m.fn_size;
   m.b1 = p; p += HID; m.ln1_w = p; p += HID; m.ln1_b = p; p += HID;
   for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) {
     m.b2[l] = p; m.ln2_w[l] = p; m.ln2_b[l] = p;
@@ -122,7 +128,8 @@ template <int LN>
 __device__ __forceinline__ void stage_vectors(float *lds, const LdsMap &m, const float *__restrict__ params, const NetOff &o,
                                               const mappo_net_desc &d) {
   const int D = d.in_dim, A = d.out_dim;
-  const int n_total = 2 * MAXD + 3 * HID * (1 + LN) + 32;
+  const int FN = m.fn_size;
+  const int n_total = 2 * FN + 3 * HID * (1 + LN) + 32;
   const int nthr = blockDim.x, tid = threadIdx.x;
   for (int e0 = 0; e0 < n_total; e0 += 4 * nthr) {
     float v[4]; int dsti[4]; bool wr[4];
@@ -131,14 +138,14 @@ __device__ __forceinline__ void stage_vectors(float *lds, const LdsMap &m, const
       const int e = e0 + j * nthr + tid;
       int src = -1; float fill = 0.f; int dst = m.fn_w;
       wr[j] = e < n_total;
-      if (e < MAXD) { dst = m.fn_w + e; if (d.use_feature_norm) { if (e < D) src = o.fn_w + e; } else fill = e < D ? 1.f : 0.f; }
-      else if (e < 2 * MAXD) { const int i = e - MAXD; dst = m.fn_b + i; if (d.use_feature_norm && i < D) src = o.fn_b + i; }
-      else if (e < 2 * MAXD + 3 * HID) { const int i = e - 2 * MAXD; dst = m.b1 + i; src = o.b1 + i; }
-      else if (e < 2 * MAXD + 3 * HID * (1 + LN)) {
-        const int i = e - 2 * MAXD - 3 * HID, l = i / (3 * HID), r = i - l * 3 * HID;
+      if (e < FN) { dst = m.fn_w + e; if (d.use_feature_norm) { if (e < D) src = o.fn_w + e; } else fill = e < D ? 1.f : 0.f; }
+      else if (e < 2 * FN) { const int i = e - FN; dst = m.fn_b + i; if (d.use_feature_norm && i < D) src = o.fn_b + i; }
+      else if (e < 2 * FN + 3 * HID) { const int i = e - 2 * FN; dst = m.b1 + i; src = o.b1 + i; }
+      else if (e < 2 * FN + 3 * HID * (1 + LN)) {
+        const int i = e - 2 * FN - 3 * HID, l = i / (3 * HID), r = i - l * 3 * HID;
         dst = (l == 0 ? m.b2[0] : m.b2[LN > 1 ? 1 : 0]) + r;
         src = (l == 0 ? o.b2[0] : o.b2[LN > 1 ? 1 : 0]) + r;
-      } else { const int i = e - 2 * MAXD - 3 * HID * (1 + LN); dst = m.bh + i; if (i < A) src = o.bh + i; }
+      } else { const int i = e - 2 * FN - 3 * HID * (1 + LN); dst = m.bh + i; if (i < A) src = o.bh + i; }
       const float ld = params[src >= 0 ? src : 0];        // unconditional load, selected below
       v[j] = src >= 0 ? ld : fill;
       dsti[j] = dst;
@@ -153,7 +160,7 @@ __device__ __forceinline__ void stage_all_weights(float *lds, const LdsMap &m, c
                                                   const NetOff &o, const mappo_net_desc &d) {
   const int D = d.in_dim, Dp = (D + 1) & ~1, A = d.out_dim;
   stage_vectors<LN>(lds, m, params, o, d);
-  stage_weight_T(lds + m.w1, params + o.w1, HID, D, Dp, WP);
+  if (D <= MAXD) stage_weight_T(lds + m.w1, params + o.w1, HID, D, Dp, WP);      // wide inputs stream W1 chunk by chunk
 #pragma unroll
   for (int l = 0; l < LN; ++l) stage_weight_T(lds + m.w2[l], params + o.w2[l], HID, HID, HID, WP);
   // head: dst[k*HP + a] = Wh[a][k]; columns a >= A are zero
@@ -227,6 +234,53 @@ __device__ __forceinline__ void commit_rows(float *tX, const RowPrefetch<WIDE> &
     const int k = 2 * j + half;
     if (k < Dp) tX[k * TP + s] = (k < D) ? (pf.v[j] - mean) * rstd : 0.f;
   }
+}
+
+// ---- wide inputs (in_dim > 64) ----
+// 64 columns [c0, c0+kc) of W1[64][D] -> sW[kk*WP + f]; rows kk in [kc, 64) zeroed.  Workgroup-cooperative, batched loads.
+__device__ __forceinline__ void stage_w1_chunk(float *dst, const float *__restrict__ w1, int D, int c0, int kc) {
+  const int nthr = blockDim.x, tid = threadIdx.x, total = HID * kc;
+  for (int e0 = 0; e0 < total; e0 += 8 * nthr) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = min(e0 + j * nthr + tid, total - 1);
+      const int f = e / kc, kk = e - f * kc;
+      v[j] = w1[f * D + c0 + kk];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int e = e0 + j * nthr + tid;
+      if (e < total) { const int f = e / kc; dst[(e - f * kc) * WP + f] = v[j]; }
+    }
+  }
+  for (int e = tid; e < HID * (MAXD - kc); e += nthr) dst[(kc + e / HID) * WP + (e % HID)] = 0.f;
+}
+
+// LayerNorm statistics of a full input row (two passes over the row, which stays in L1/L2 between them)
+__device__ __forceinline__ void wide_row_stats(const float *__restrict__ xr, int D, bool ok, int half, bool feature_norm, float &mean,
+                                               float &rstd) {
+  mean = 0.f; rstd = 1.f;
+  if (!feature_norm) return;
+  float s0 = 0.f;
+  if (ok) for (int k = half; k < D; k += 2) s0 += xr[k];
+  mean = xhalf_sum(s0) / (float)D;
+  float q = 0.f;
+  if (ok) for (int k = half; k < D; k += 2) { const float c = xr[k] - mean; q += c * c; }
+  rstd = 1.0f / sqrtf(xhalf_sum(q) / (float)D + LN_EPS);
+}
+
+// tX[kk][s] <- xhat0 of columns [c0, c0+64) of this lane's row
+__device__ __forceinline__ void wide_commit_chunk(float *tX, const float *__restrict__ xr, int D, int c0, bool ok, float mean, float rstd,
+                                                  int l31, int half) {
+  float v[TS];
+#pragma unroll
+  for (int j = 0; j < TS; ++j) {
+    const int k = c0 + 2 * j + half;
+    v[j] = (ok && k < D) ? xr[k] : mean;          // (mean - mean) * rstd = 0 for padding
+  }
+#pragma unroll
+  for (int j = 0; j < TS; ++j) tX[(2 * j + half) * TP + l31] = (v[j] - mean) * rstd;
 }
 
 // acc (2 tiles of 32 features) <- bias
@@ -303,12 +357,41 @@ __device__ __forceinline__ int ln_b_of(const LdsMap &m, int l) { return l == 0 ?
 
 // forward of one 32-sample tile: tX (xhat0) -> tH[0..LN] (xhat of every LayerNorm); statistics kept for backward
 template <bool RELU, int LN>
+__device__ __forceinline__ void tile_forward_rest(const float *lds, const LdsMap &m, float *tH, f32x16 (&acc)[2], int l31, int half,
+                                                  TileStats<LN> &st);
+
+template <bool RELU, int LN>
 __device__ __forceinline__ void tile_forward(const float *lds, const LdsMap &m, float *tX, float *tH, int D, int l31, int half,
                                              TileStats<LN> &st) {
   const int Dp = (D + 1) & ~1;
   f32x16 acc[2];
   init_bias(acc, lds + m.b1, half);
   layer_mfma(acc, lds + m.w1, tX, lds + m.fn_w, lds + m.fn_b, Dp / 2, l31, half);
+  tile_forward_rest<RELU, LN>(lds, m, tH, acc, l31, half, st);
+}
+
+// wide inputs: layer 1 accumulated over 64-column chunks; every wave of the workgroup must call this the same
+// number of times (block barriers around the shared W1 chunk)
+template <bool RELU, int LN>
+__device__ __forceinline__ void tile_forward_wide(float *lds, const LdsMap &m, const float *__restrict__ w1, const float *__restrict__ xr,
+                                                  bool ok, float mean0, float rstd0, float *tX, float *tH, int D, int l31, int half,
+                                                  TileStats<LN> &st) {
+  f32x16 acc[2];
+  init_bias(acc, lds + m.b1, half);
+  for (int c0 = 0; c0 < D; c0 += MAXD) {
+    const int kc = min(MAXD, D - c0);
+    __syncthreads();                                   // the previous chunk of W1 is no longer being read
+    stage_w1_chunk(lds + m.w1, w1, D, c0, kc);
+    wide_commit_chunk(tX, xr, D, c0, ok, mean0, rstd0, l31, half);
+    __syncthreads();
+    layer_mfma(acc, lds + m.w1, tX, lds + m.fn_w + c0, lds + m.fn_b + c0, (kc + 1) / 2, l31, half);
+  }
+  tile_forward_rest<RELU, LN>(lds, m, tH, acc, l31, half, st);
+}
+
+template <bool RELU, int LN>
+__device__ __forceinline__ void tile_forward_rest(const float *lds, const LdsMap &m, float *tH, f32x16 (&acc)[2], int l31, int half,
+                                                  TileStats<LN> &st) {
   act_ln_stats<RELU>(acc, st.mean[0], st.rstd[0]);
   st.pos[0] = positive_mask(acc);
   xhat_to_tile(tH, acc, st.mean[0], st.rstd[0], l31, half);
@@ -360,9 +443,11 @@ struct FwdArgs {
   const uint64_t *counter_dev;   // optional device word added to `counter` (lets a captured hipGraph draw fresh numbers)
 };
 
-template <bool RELU, int LN, int MODE, bool WIDE>
+// XW: 0 = in_dim <= 32, 1 = in_dim <= 64 (rows prefetched into registers), 2 = in_dim > 64 (K-chunked layer 1)
+template <bool RELU, int LN, int MODE, int XW>
 __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
   extern __shared__ __align__(16) float lds[];
+  constexpr bool WIDE = XW >= 1, XWIDE = XW == 2;
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
@@ -370,22 +455,34 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
   const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
   const int64_t n_tiles = (p.B + TS - 1) / TS;
   const int64_t tile_stride = (int64_t)gridDim.x * n_waves;
-  int64_t tile = (int64_t)blockIdx.x * n_waves + wave;
+  const int64_t n_btiles = (n_tiles + n_waves - 1) / n_waves;    // the tile loop is uniform over the workgroup's waves
   RowPrefetch<WIDE> pf;
-  prefetch_rows(pf, p.x, p.rows, tile * TS, p.B, D, lane);       // in flight while the weights are staged
+  if (!XWIDE) prefetch_rows(pf, p.x, p.rows, ((int64_t)blockIdx.x * n_waves + wave) * TS, p.B, D, lane);   // under the staging
   stage_all_weights<LN>(lds, m, p.params, o, p.desc);
   __syncthreads();
   float *tX = lds + m.tiles + wave * m.wave_stride;
   float *tH = tX + m.x_rows * TP;
   float *tZ = tH + (LN + 1) * HID * TP;
-  for (; tile < n_tiles; tile += tile_stride) {
+  for (int64_t tb = blockIdx.x; tb < n_btiles; tb += gridDim.x) {
+    const int64_t tile = tb * n_waves + wave;
     const int64_t base = tile * TS;
-    const int n_valid = pf.n_valid;
-    commit_rows(tX, pf, D, Dp, lane, p.desc.use_feature_norm != 0);
-    wave_lds_sync();
-    prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);
+    int n_valid;
     TileStats<LN> st;
-    tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
+    if (!XWIDE) {
+      n_valid = pf.n_valid;
+      commit_rows(tX, pf, D, Dp, lane, p.desc.use_feature_norm != 0);
+      wave_lds_sync();
+      prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);
+      tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
+    } else {
+      n_valid = (int)max((int64_t)0, min((int64_t)TS, p.B - base));
+      const bool ok = l31 < n_valid;
+      const int64_t row = ok ? (p.rows ? (int64_t)p.rows[base + l31] : base + l31) : 0;
+      const float *xr = p.x + row * D;
+      float mean0, rstd0;
+      wide_row_stats(xr, D, ok, half, p.desc.use_feature_norm != 0, mean0, rstd0);
+      tile_forward_wide<RELU, LN>(lds, m, p.params + o.w1, xr, ok, mean0, rstd0, tX, tH, D, l31, half, st);
+    }
     if (MODE == 2) {
       // trunk features (LayerNorm output of the last layer, affine applied) feature-major: out[f][B], the input
       // layout of the GRU kernels (gru.hip); a register's 32 lanes write one 128-B segment
@@ -468,7 +565,9 @@ struct UpdArgs {
   LdsMap map;
   int64_t B;
   int n_regions;             // LDS regions of P floats used for the end-of-kernel reduction (2 when they fit)
-  int p_red;                 // number of leading flat parameters this launch owns (trunk only for HEAD 3)
+  int p_red;                 // end of the flat parameter range this launch reduces (trunk only for HEAD 3)
+  int red_base;              // start of that range (b1 for wide inputs: W1 / feature-norm grads come from wide_l1_bwd_kernel)
+  float *wide_ws;            // wide inputs: [64][B] dz1 (feature-major) | mean0[B] | rstd0[B]
   const float *dHT;          // HEAD 3: gradient w.r.t. the trunk output, feature-major [64][B]
   // HEAD 0
   const float *dout;
@@ -558,12 +657,11 @@ struct LossPrefetch {
   uint32_t dead;            // actor: bit a set <=> available_actions[a] == 0
 };
 
-template <int HEAD, bool WIDE>
-__device__ __forceinline__ void prefetch_loss(LossPrefetch &lp, const UpdArgs &p, const RowPrefetch<WIDE> &pf, int lane, int A) {
+template <int HEAD>
+__device__ __forceinline__ void prefetch_loss(LossPrefetch &lp, const UpdArgs &p, int64_t row, int n_valid, int lane, int A) {
   lp.f0 = lp.f1 = lp.f2 = lp.f3 = 0.f;
   lp.dead = 0u;
-  if (HEAD == 0 || HEAD == 3 || lane >= pf.n_valid) return;        // lanes 0..31 carry the per-sample loss inputs
-  const int64_t row = pf.my_row;
+  if (HEAD == 0 || HEAD == 3 || lane >= n_valid) return;        // lanes 0..31 carry the per-sample loss inputs
   if (HEAD == 1) {
     lp.f0 = p.actions[row]; lp.f1 = p.old_logp[row]; lp.f2 = p.adv[row]; lp.f3 = p.active[row];
     if (p.avail) {
@@ -575,10 +673,11 @@ __device__ __forceinline__ void prefetch_loss(LossPrefetch &lp, const UpdArgs &p
   }
 }
 
-template <bool RELU, int LN, int HEAD, bool WIDE>
+template <bool RELU, int LN, int HEAD, int XW>
 __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   extern __shared__ __align__(16) float lds[];
   __shared__ double red_smem[16 * 4];
+  constexpr bool WIDE = XW >= 1, XWIDE = XW == 2;
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
@@ -587,12 +686,14 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   constexpr bool wide = WIDE;        // second 32-wide tile over the input features in use
   const int64_t n_tiles = (p.B + TS - 1) / TS;
   const int64_t tile_stride = (int64_t)gridDim.x * n_waves;
-  int64_t tile = (int64_t)blockIdx.x * n_waves + wave;
+  const int64_t n_btiles = (n_tiles + n_waves - 1) / n_waves;    // uniform tile loop (block barriers in the wide path)
   RowPrefetch<WIDE> pf;
   LossPrefetch lp;
   STAMP_DECL
-  prefetch_rows(pf, p.x, p.rows, tile * TS, p.B, D, lane);
-  prefetch_loss<HEAD, WIDE>(lp, p, pf, lane, A);
+  if (!XWIDE) {
+    prefetch_rows(pf, p.x, p.rows, ((int64_t)blockIdx.x * n_waves + wave) * TS, p.B, D, lane);
+    prefetch_loss<HEAD>(lp, p, pf.my_row, pf.n_valid, lane, A);
+  }
   stage_all_weights<LN>(lds, m, p.params, o, p.desc);
   __syncthreads();
   STAMP(0);   // staging
@@ -625,17 +726,32 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 #pragma unroll
   for (int l = 0; l <= LN; ++l) { gB[l] = 0.f; gLnW[l] = 0.f; gLnB[l] = 0.f; }
 
-  for (; tile < n_tiles; tile += tile_stride) {
+  for (int64_t tb = blockIdx.x; tb < n_btiles; tb += gridDim.x) {
+    const int64_t tile = tb * n_waves + wave;
     const int64_t base = tile * TS;
-    const int n_valid = pf.n_valid;
-    const LossPrefetch cur = lp;
-    commit_rows(tX, pf, D, Dp, lane, p.desc.use_feature_norm != 0);
-    wave_lds_sync();
-    prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);   // next tile, hidden under the MFMAs below
-    prefetch_loss<HEAD, WIDE>(lp, p, pf, lane, A);
-    STAMP(1);   // commit (+ feature norm) + prefetch issue
+    int n_valid;
+    LossPrefetch cur;
     TileStats<LN> st;
-    tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
+    float mean0 = 0.f, rstd0 = 1.f;
+    if (!XWIDE) {
+      n_valid = pf.n_valid;
+      cur = lp;
+      commit_rows(tX, pf, D, Dp, lane, p.desc.use_feature_norm != 0);
+      wave_lds_sync();
+      prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);   // next tile, hidden under the MFMAs below
+      prefetch_loss<HEAD>(lp, p, pf.my_row, pf.n_valid, lane, A);
+      STAMP(1);   // commit (+ feature norm) + prefetch issue
+      tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
+    } else {
+      n_valid = (int)max((int64_t)0, min((int64_t)TS, p.B - base));
+      const bool ok = l31 < n_valid;
+      const int64_t row = ok ? (p.rows ? (int64_t)p.rows[base + l31] : base + l31) : 0;
+      prefetch_loss<HEAD>(cur, p, row, n_valid, lane, A);
+      const float *xr = p.x + row * D;
+      wide_row_stats(xr, D, ok, half, p.desc.use_feature_norm != 0, mean0, rstd0);
+      STAMP(1);
+      tile_forward_wide<RELU, LN>(lds, m, p.params + o.w1, xr, ok, mean0, rstd0, tX, tH, D, l31, half, st);
+    }
     float *tLast = tH + LN * HID * TP;
     STAMP(2);   // trunk forward
 
@@ -757,6 +873,20 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
       ln_act_backward<RELU>(dH, tCur, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW[0], gLnB[0], lane, l31, half);
       gB[0] += tile_row_sum(tCur, lane);
       STAMP(8);   // LN + act backward (layer 1)
+      if (XWIDE) {
+        // wide inputs: dz1 (feature-major) and the row statistics go to HBM; wide_l1_bwd_kernel turns them into
+        // dW1 and the feature-norm gradients (64 x in_dim accumulators do not fit one wave's registers)
+        float *dz1T = p.wide_ws, *stats = p.wide_ws + (int64_t)HID * p.B;
+        if (l31 < n_valid) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dz1T[(int64_t)(32 * t + ROWMAP(r, half)) * p.B + base + l31] = dH[t][r];
+          if (half == 0) { stats[base + l31] = mean0; stats[p.B + base + l31] = rstd0; }
+        }
+        wave_lds_sync();
+        continue;
+      }
       // dW1[f_out][k] += sum_s dz1[f_out][s] * xn[k][s],  xn = xhat0 * gamma0 + beta0
       {
         const int k0 = l31, k1 = 32 + l31;
@@ -830,8 +960,9 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 
   // ---- reduce the waves' accumulators through LDS (two regions, waves pair up) and write the slab ----
   __syncthreads();
-  const int P = p.p_red;
-  float *red0 = lds + m.tiles;                     // n_regions * P floats fit in the tile area (checked on the host)
+  const int rb = p.red_base;                         // first flat parameter this launch reduces (0, or b1 for wide inputs)
+  const int P = p.p_red - rb;
+  float *red0 = lds + m.tiles - rb;                  // indexed by absolute flat offsets >= rb                     // n_regions * P floats fit in the tile area (checked on the host)
   const int n_reg = p.n_regions;
   for (int round = 0; round < (n_waves + n_reg - 1) / n_reg; ++round) {
     if (wave / n_reg == round) {
@@ -851,7 +982,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) {
           const int col = 32 * tj + l31, row0 = 32 * ti + 4 * half;
-          red_tile(gW1[ti][tj], o.w1 + row0 * D + col, D, col < D);
+          if (!XWIDE) red_tile(gW1[ti][tj], o.w1 + row0 * D + col, D, col < D);
 #pragma unroll
           for (int l = 0; l < LN; ++l) red_tile(gW2[l][ti][tj], o.w2[l] + row0 * HID + col, HID, true);
         }
@@ -878,7 +1009,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
           vals[n] = gLnB[l + 1]; idx[n] = o.ln2_b[l] + lane; ok[n++] = true;
         }
         vals[n] = gBh; idx[n] = (HEAD != 3) ? o.bh + l31 : 0; ok[n++] = (HEAD != 3 && half == 0 && l31 < A);
-        const bool fn = p.desc.use_feature_norm && lane < D;
+        const bool fn = !XWIDE && p.desc.use_feature_norm && lane < D;
         vals[n] = gFnW; idx[n] = o.fn_w + lane; ok[n++] = fn;
         vals[n] = gFnB; idx[n] = o.fn_b + lane; ok[n++] = fn;
         float old[3 * (LN + 1) + 3];
@@ -890,11 +1021,12 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     }
     __syncthreads();
   }
-  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0 + rb;
+  const float *redv = red0 + rb;
   if (n_reg > 1) {
-    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red0[e] + red0[P + e];
+    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = redv[e] + redv[P + e];
   } else {
-    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red0[e];
+    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = redv[e];
   }
   STAMP(12);    // block reduction + slab write
   STAMP_FLUSH();
@@ -906,8 +1038,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 static int check_desc_common(const mappo_net_desc *d, const char *who) {
   MAPPO_REQUIRE(d, "%s: null desc", who);
   MAPPO_REQUIRE(d->hidden == HID, "%s: hidden_size %d unsupported (kernels are tiled for %d)", who, d->hidden, HID);
-  MAPPO_REQUIRE(d->in_dim >= 1 && d->in_dim <= MAXD, "%s: in_dim %d outside [1,%d] (wide-input path not built)", who,
-                d->in_dim, MAXD);
+  MAPPO_REQUIRE(d->in_dim >= 1 && d->in_dim <= MAPPO_MAX_IN_DIM, "%s: in_dim %d outside [1,%d]", who, d->in_dim, MAPPO_MAX_IN_DIM);
   MAPPO_REQUIRE(d->out_dim >= 1 && d->out_dim <= MAPPO_MAX_ACTIONS, "%s: out_dim %d outside [1,%d]", who, d->out_dim,
                 MAPPO_MAX_ACTIONS);
   MAPPO_REQUIRE(d->layer_N >= 0 && d->layer_N <= MAPPO_MAX_LAYER_N, "%s: layer_N %d outside [0,%d]", who, d->layer_N,
@@ -958,8 +1089,9 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
     }                                                                                                          \
     PROF_LAUNCH(prof_id, (mlp_forward_kernel<R, L, MODE, W>), grid, block, lds_bytes, st, a);                   \
   } while (0)
-#define FWD_W(R, L) do { if (wide) FWD2(R, L, true); else FWD2(R, L, false); } while (0)
-  const bool relu = a.desc.use_relu != 0, wide = a.desc.in_dim > 32;
+#define FWD_W(R, L) do { if (xw == 2) FWD2(R, L, 2); else if (xw == 1) FWD2(R, L, 1); else FWD2(R, L, 0); } while (0)
+  const bool relu = a.desc.use_relu != 0;
+  const int xw = a.desc.in_dim > MAXD ? 2 : (a.desc.in_dim > 32 ? 1 : 0);
   const int prof_id = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
   if (LN == 0) { if (relu) FWD_W(true, 0); else FWD_W(false, 0); }
   else if (LN == 1) { if (relu) FWD_W(true, 1); else FWD_W(false, 1); }
@@ -1019,8 +1151,11 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
   a.p_red = (HEAD == 3 && d.recurrent) ? a.off.gru_wih : a.off.total;
-  a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * a.p_red) ? 2 : 1;
-  MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * a.p_red, "%s: reduction buffer too small", who);
+  a.red_base = d.in_dim > MAXD ? a.off.b1 : 0;
+  MAPPO_REQUIRE(d.in_dim <= MAXD || a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
+  const int p_span = a.p_red - a.red_base;
+  a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * p_span) ? 2 : 1;
+  MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * p_span, "%s: reduction buffer too small", who);
   const int nb = mappo_mlp_backward_slabs(a.B);    // every slab the caller sized for is written: grid == that count
   dim3 grid((unsigned)nb), block(WAVE * nw);
 #define UPD2(R, L, W)                                                                                      \
@@ -1034,8 +1169,9 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
     }                                                                                                      \
     PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update_kernel<R, L, HEAD, W>), grid, block, lds_bytes, st, a);     \
   } while (0)
-#define UPD(R, L) do { if (wide) UPD2(R, L, true); else UPD2(R, L, false); } while (0)
-  const bool relu = d.use_relu != 0, wide = d.in_dim > 32;
+#define UPD(R, L) do { if (xw == 2) UPD2(R, L, 2); else if (xw == 1) UPD2(R, L, 1); else UPD2(R, L, 0); } while (0)
+  const bool relu = d.use_relu != 0;
+  const int xw = d.in_dim > MAXD ? 2 : (d.in_dim > 32 ? 1 : 0);
   if (LN == 0) { if (relu) UPD(true, 0); else UPD(false, 0); }
   else if (LN == 1) { if (relu) UPD(true, 1); else UPD(false, 1); }
   else { if (relu) UPD(true, 2); else UPD(false, 2); }
@@ -1047,23 +1183,23 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
 
 extern "C" int mappo_mlp_backward(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
                                   int64_t B, const float *dout, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                                  mappo_stream_t stream) {
+                                  float *wide_ws, mappo_stream_t stream) {
   if (int rc = check_desc(desc, "mlp_backward")) return rc;
   MAPPO_REQUIRE(params && x && dout && slabs && B > 0, "mlp_backward: bad arguments");
   UpdArgs a = {};
   a.params = params; a.x = x; a.rows = rows; a.dout = dout; a.slabs = slabs; a.slab_stride = slab_stride;
-  a.slab_col0 = slab_col0; a.desc = *desc; a.B = B;
+  a.slab_col0 = slab_col0; a.desc = *desc; a.B = B; a.wide_ws = wide_ws;
   return launch_update<0>(a, as_stream(stream), "mlp_backward");
 }
 
 extern "C" int mappo_trunk_backward(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
                                     int64_t B, const float *dHT, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                                    mappo_stream_t stream) {
+                                    float *wide_ws, mappo_stream_t stream) {
   if (int rc = check_desc_trunk(desc, "trunk_backward")) return rc;
   MAPPO_REQUIRE(params && x && dHT && slabs && B > 0, "trunk_backward: bad arguments");
   UpdArgs a = {};
   a.params = params; a.x = x; a.rows = rows; a.dHT = dHT; a.slabs = slabs; a.slab_stride = slab_stride;
-  a.slab_col0 = slab_col0; a.desc = *desc; a.B = B;
+  a.slab_col0 = slab_col0; a.desc = *desc; a.B = B; a.wide_ws = wide_ws;
   return launch_update<3>(a, as_stream(stream), "trunk_backward");
 }
 
@@ -1073,14 +1209,14 @@ extern "C" int mappo_actor_update(const float *params, const mappo_net_desc *des
                                   int64_t B, const float *avail, const float *actions, const float *old_logp,
                                   const float *adv, const float *active, const double *mb_moments,
                                   const mappo_ppo_cfg *cfg, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                                  double *partials, mappo_stream_t stream) {
+                                  double *partials, float *wide_ws, mappo_stream_t stream) {
   if (int rc = check_desc(desc, "actor_update")) return rc;
   MAPPO_REQUIRE(params && obs && actions && old_logp && adv && active && mb_moments && cfg && slabs && partials && B > 0,
                 "actor_update: bad arguments");
   UpdArgs a = {};
   a.params = params; a.x = obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
   a.desc = *desc; a.B = B; a.avail = avail; a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.active = active;
-  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg;
+  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg; a.wide_ws = wide_ws;
   return launch_update<1>(a, as_stream(stream), "actor_update");
 }
 
@@ -1088,7 +1224,7 @@ extern "C" int mappo_critic_update(const float *params, const mappo_net_desc *de
                                    const int32_t *rows, int64_t B, const float *v_old, const float *returns,
                                    const float *active, const float *vn_state, const double *mb_moments,
                                    const mappo_ppo_cfg *cfg, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                                   double *partials, mappo_stream_t stream) {
+                                   double *partials, float *wide_ws, mappo_stream_t stream) {
   if (int rc = check_desc(desc, "critic_update")) return rc;
   MAPPO_REQUIRE(desc->out_dim == 1, "critic_update: out_dim must be 1");
   MAPPO_REQUIRE(params && share_obs && v_old && returns && active && mb_moments && cfg && slabs && partials && B > 0,
@@ -1097,8 +1233,183 @@ extern "C" int mappo_critic_update(const float *params, const mappo_net_desc *de
   UpdArgs a = {};
   a.params = params; a.x = share_obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
   a.desc = *desc; a.B = B; a.v_old = v_old; a.returns = returns; a.active = active; a.vn_state = vn_state;
-  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg;
+  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg; a.wide_ws = wide_ws;
   return launch_update<2>(a, as_stream(stream), "critic_update");
+}
+
+// ------------------------------------------------------------------------------------------------
+// wide_l1_bwd_kernel: layer-1 weight gradient and feature-norm gradients for in_dim > 64.
+//   dW1[f][k]  = sum_s dz1[f][s] * xn[k][s],   xn = xhat0 * gamma0 + beta0
+//   dxn[k][s]  = sum_f W1[f][k] * dz1[f][s] ;  dgamma0[k] = sum_s dxn * xhat0 ;  dbeta0[k] = sum_s dxn
+// A workgroup owns ONE 64-column chunk of W1 (blockIdx.y) and one share of the row tiles (blockIdx.x); its 4 waves
+// walk row tiles, keep the chunk's 64x64 dW1 block in registers, and the per-sample-lane partial sums of the
+// feature-norm gradients are reduced across lanes once at the end.  One slab row per blockIdx.x.
+// ------------------------------------------------------------------------------------------------
+struct WideArgs {
+  const float *params, *x;
+  const int32_t *rows;
+  const float *wide_ws;
+  float *slabs;
+  int64_t slab_stride, slab_col0;
+  NetOff off;
+  int64_t B;
+  int D, use_feature_norm;
+};
+
+__global__ __launch_bounds__(256, 1) void wide_l1_bwd_kernel(WideArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  const int D = p.D, c0 = blockIdx.y * MAXD, kc = min(MAXD, D - c0);
+  float *sW = lds;                                   // [64 kk][WP]  W1 chunk, k-major
+  float *sG = sW + MAXD * WP, *sBt = sG + MAXD;      // gamma0 / beta0 of the chunk
+  float *tD = sBt + MAXD + wave * (2 * HID * TP);    // [64 f][TP]   dz1 tile
+  float *tXc = tD + HID * TP;                        // [64 kk][TP]  xhat0 tile of the chunk
+  stage_w1_chunk(sW, p.params + p.off.w1, D, c0, kc);
+  for (int e = threadIdx.x; e < MAXD; e += blockDim.x) {
+    const bool in = e < kc;
+    sG[e] = in ? (p.use_feature_norm ? p.params[p.off.fn_w + c0 + e] : 1.f) : 0.f;
+    sBt[e] = (in && p.use_feature_norm) ? p.params[p.off.fn_b + c0 + e] : 0.f;
+  }
+  __syncthreads();
+  const float *dz1T = p.wide_ws, *stats = p.wide_ws + (int64_t)HID * p.B;
+  f32x16 gW[2][2], accB[2], accG[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accB[i][r] = 0.f; accG[i][r] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gW[i][j][r] = 0.f;
+  }
+  const int64_t n_tiles = (p.B + TS - 1) / TS;
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < n_tiles; tile += (int64_t)gridDim.x * 4) {
+    const int64_t base = tile * TS;
+    const int n_valid = (int)min((int64_t)TS, p.B - base);
+    const bool ok = l31 < n_valid;
+    // dz1 tile [f][s] (feature-major source: 128-B segments)
+    for (int e = lane; e < HID * TS; e += WAVE) {
+      const int f = e >> 5, s = e & 31;
+      tD[f * TP + s] = (s < n_valid) ? dz1T[(int64_t)f * p.B + base + s] : 0.f;
+    }
+    const int64_t row = ok ? (p.rows ? (int64_t)p.rows[base + l31] : base + l31) : 0;
+    const float mean0 = ok ? stats[base + l31] : 0.f, rstd0 = ok ? stats[p.B + base + l31] : 1.f;
+    wide_commit_chunk(tXc, p.x + row * D, D, c0, ok, mean0, rstd0, l31, half);
+    wave_lds_sync();
+    // dW1 chunk
+    {
+      const float g0 = sG[l31], b0 = sBt[l31], g1 = sG[32 + l31], b1 = sBt[32 + l31];
+#pragma unroll 2
+      for (int ss = 0; ss < TS / 2; ++ss) {
+        const int s = 2 * ss + half;
+        const float a0 = tD[l31 * TP + s], a1 = tD[(32 + l31) * TP + s];
+        // padding samples carry dz1 = 0, padding columns carry gamma = beta = 0
+        const float x0 = tXc[l31 * TP + s] * g0 + b0, x1 = tXc[(32 + l31) * TP + s] * g1 + b1;
+        gW[0][0] = mfma(a0, x0, gW[0][0]);
+        gW[0][1] = mfma(a0, x1, gW[0][1]);
+        gW[1][0] = mfma(a1, x0, gW[1][0]);
+        gW[1][1] = mfma(a1, x1, gW[1][1]);
+      }
+    }
+    if (p.use_feature_norm) {
+      f32x16 dX[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dX[t][r] = 0.f;
+#pragma unroll 4
+      for (int ff = 0; ff < HID / 2; ++ff) {
+        const int f = 2 * ff + half;
+        const float b = tD[f * TP + l31];
+        dX[0] = mfma(sW[l31 * WP + f], b, dX[0]);
+        dX[1] = mfma(sW[(32 + l31) * WP + f], b, dX[1]);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          accB[t][r] += dX[t][r];
+          accG[t][r] += dX[t][r] * tXc[(32 * t + ROWMAP(r, half)) * TP + l31];
+        }
+    }
+    wave_lds_sync();
+  }
+  // ---- cross-lane (sample) reduction of the feature-norm partial sums, through this wave's tiles ----
+  float gFnB = 0.f, gFnW = 0.f;
+  if (p.use_feature_norm) {
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        tD[(32 * t + ROWMAP(r, half)) * TP + l31] = accB[t][r];
+        tXc[(32 * t + ROWMAP(r, half)) * TP + l31] = accG[t][r];
+      }
+    wave_lds_sync();
+    for (int j = 0; j < TS; ++j) { gFnB += tD[lane * TP + j]; gFnW += tXc[lane * TP + j]; }
+  }
+  // ---- reduce the 4 waves through LDS (reusing wave 0's tiles), write this workgroup's slab columns ----
+  __syncthreads();
+  float *red = sBt + MAXD;                           // >= 64*64 + 128 floats available (4 waves x 2 tiles)
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          float old[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) old[r] = (w == 0) ? 0.f : red[(32 * ti + ROWMAP(r, half)) * MAXD + 32 * tj + l31];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(32 * ti + ROWMAP(r, half)) * MAXD + 32 * tj + l31] = old[r] + gW[ti][tj][r];
+        }
+      const float ob = (w == 0) ? 0.f : red[HID * MAXD + lane], og = (w == 0) ? 0.f : red[HID * MAXD + MAXD + lane];
+      red[HID * MAXD + lane] = ob + gFnB;
+      red[HID * MAXD + MAXD + lane] = og + gFnW;
+    }
+    __syncthreads();
+  }
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
+  for (int e = threadIdx.x; e < HID * kc; e += blockDim.x) {
+    const int f = e / kc, kk = e - f * kc;
+    slab[p.off.w1 + f * D + c0 + kk] = red[f * MAXD + kk];
+  }
+  if (p.use_feature_norm)
+    for (int e = threadIdx.x; e < kc; e += blockDim.x) {
+      slab[p.off.fn_b + c0 + e] = red[HID * MAXD + e];
+      slab[p.off.fn_w + c0 + e] = red[HID * MAXD + MAXD + e];
+    }
+}
+
+extern "C" int64_t mappo_wide_workspace_floats(int64_t B) { return (int64_t)(HID + 2) * B; }
+
+extern "C" int32_t mappo_wide_l1_slabs(int64_t B) {
+  const int64_t n_tiles = (B + TS - 1) / TS, groups = (n_tiles + 3) / 4;
+  return (int32_t)(groups < 32 ? groups : 32);
+}
+
+extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
+                                      int64_t B, const float *wide_ws, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                                      mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(desc, "wide_l1_backward")) return rc;
+  MAPPO_REQUIRE(desc->in_dim > MAXD, "wide_l1_backward: in_dim %d is handled inside the update kernels", desc->in_dim);
+  MAPPO_REQUIRE(params && x && wide_ws && slabs && B > 0, "wide_l1_backward: bad arguments");
+  MAPPO_CLEAR_STICKY();
+  WideArgs a = {};
+  a.params = params; a.x = x; a.rows = rows; a.wide_ws = wide_ws; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
+  a.off = net_offsets(*desc); a.B = B; a.D = desc->in_dim; a.use_feature_norm = desc->use_feature_norm;
+  MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "wide_l1_backward: slab column range");
+  const size_t lds_bytes = (size_t)(MAXD * WP + 2 * MAXD + 4 * 2 * HID * TP) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("wide_l1_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr = true;
+  }
+  dim3 grid((unsigned)mappo_wide_l1_slabs(B), (unsigned)((desc->in_dim + MAXD - 1) / MAXD));
+  hipLaunchKernelGGL(wide_l1_bwd_kernel, grid, dim3(256), lds_bytes, as_stream(stream), a);
+  MAPPO_CHECK_LAUNCH("wide_l1_backward");
+  return MAPPO_OK;
 }
 
 // statistics of one fused update from the two kernels' per-workgroup partial sums (same layout as

@@ -127,10 +127,40 @@ def mlp_backward_slabs(B):
     return int(_lib.load().mappo_mlp_backward_slabs(int(B)))
 
 
+def _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, wide_ws):
+    """Second launch of a wide-input (in_dim > 64) backward: W1 + feature-norm gradient columns."""
+    if desc.in_dim > 64:
+        rc = _lib.load().mappo_wide_l1_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(B),
+                                                _ptr(wide_ws), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+        _lib.check(rc, "mappo_wide_l1_backward")
+
+
+_wide_ws_cache = {}
+
+
+def wide_workspace(desc, B, device):
+    """Scratch of the wide-input path (None for in_dim <= 64), cached per (B, device)."""
+    if desc.in_dim <= 64:
+        return None
+    key = (int(B), str(device))
+    ws = _wide_ws_cache.get(key)
+    if ws is None:
+        ws = torch.empty(int(_lib.load().mappo_wide_workspace_floats(int(B))), dtype=torch.float32, device=device)
+        _wide_ws_cache[key] = ws
+    return ws
+
+
+def wide_l1_slabs(B):
+    return int(_lib.load().mappo_wide_l1_slabs(int(B)))
+
+
 def mlp_backward(params, desc, x, rows, B, dout, slabs, slab_stride, slab_col0):
+    ws = wide_workspace(desc, B, x.device)
     rc = _lib.load().mappo_mlp_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True),
-                                        int(B), _ptr(dout), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+                                        int(B), _ptr(dout), _ptr(slabs), int(slab_stride), int(slab_col0),
+                                        _ptr(ws, allow_none=True), _stream())
     _lib.check(rc, "mappo_mlp_backward")
+    _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, ws)
 
 
 # ---- fused update kernels ------------------------------------------------------------------------
@@ -140,20 +170,24 @@ def update_partials(device):
 
 def actor_update(params, desc, obs, rows, B, avail, actions, old_logp, adv, active, mb_moments, cfg, slabs, slab_stride,
                  slab_col0, partials):
+    ws = wide_workspace(desc, B, obs.device)
     rc = _lib.load().mappo_actor_update(_ptr(params), C.byref(desc), _ptr(obs), _ptr(rows, torch.int32, allow_none=True), int(B),
                                         _ptr(avail, allow_none=True), _ptr(actions), _ptr(old_logp), _ptr(adv), _ptr(active),
                                         _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(slabs), int(slab_stride),
-                                        int(slab_col0), _ptr(partials, torch.float64), _stream())
+                                        int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), _stream())
     _lib.check(rc, "mappo_actor_update")
+    _wide(desc, obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
 
 
 def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_state, mb_moments, cfg, slabs, slab_stride,
                   slab_col0, partials):
+    ws = wide_workspace(desc, B, share_obs.device)
     rc = _lib.load().mappo_critic_update(_ptr(params), C.byref(desc), _ptr(share_obs), _ptr(rows, torch.int32, allow_none=True),
                                          int(B), _ptr(v_old), _ptr(returns), _ptr(active), _ptr(vn_state, allow_none=True),
                                          _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(slabs), int(slab_stride),
-                                         int(slab_col0), _ptr(partials, torch.float64), _stream())
+                                         int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), _stream())
     _lib.check(rc, "mappo_critic_update")
+    _wide(desc, share_obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
 
 
 def update_stats(actor_partials, n_actor, critic_partials, n_critic, mb_moments, cfg, stats):
@@ -212,9 +246,11 @@ def gru_wgrad(desc, featT, scratch, dgiT, dghnT, L, Nc, slabs, slab_stride, slab
 
 
 def trunk_backward(params, desc, x, rows, B, dxT, slabs, slab_stride, slab_col0):
+    ws = wide_workspace(desc, B, x.device)
     rc = _lib.load().mappo_trunk_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(B),
-                                          _ptr(dxT), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+                                          _ptr(dxT), _ptr(slabs), int(slab_stride), int(slab_col0), _ptr(ws, allow_none=True), _stream())
     _lib.check(rc, "mappo_trunk_backward")
+    _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, ws)
 
 
 # ---- K10 / K11 ------------------------------------------------------------------------------------

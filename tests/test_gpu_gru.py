@@ -219,3 +219,50 @@ def test_recurrent_runner_iteration_vs_oracle(M, runner_kind):
         close(vv, opol.actor.state_dict()[k].numpy(), 1e-4, 6e-6, k)
     for k, vv in runner.policy.critic.state_dict().items():
         close(vv, opol.critic.state_dict()[k].numpy(), 1e-4, 6e-6, k)
+
+
+@pytest.mark.parametrize("rec", [False, True])
+def test_wide_observation_train_vs_oracle(M, rec):
+    """SMAC MMM2 shapes (BASELINE configs[3]: 10 agents, obs 176, share_obs 322, 18 actions), MLP and GRU policies:
+    R_MAPPO.train through the K-chunked layer-1 kernels + wide_l1_backward against the oracle."""
+    T, N, Ma, D, S, A, L = 10, 3, 10, 176, 322, 18, 10
+    a = make_args(M, episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=2, num_mini_batch=1,
+                  use_recurrent_policy=rec, data_chunk_length=L, perm_device="cpu", gain=1.0)
+    torch.manual_seed(9)
+    pol = M.R_MAPPOPolicy(a, [D], [S], M.Discrete(A))
+    tr = M.R_MAPPO(a, pol)
+    buf = M.SharedReplayBuffer(a, Ma, [D], [S], M.Discrete(A))
+    rng = np.random.default_rng(4)
+    f = np.float32
+    for n in ("share_obs", "obs", "rnn_states", "rnn_states_critic"):
+        arr = getattr(buf, n); arr.copy_(torch.from_numpy(rng.standard_normal(tuple(arr.shape)).astype(f)))
+    buf.value_preds.copy_(torch.from_numpy((rng.standard_normal(tuple(buf.value_preds.shape)) * 0.3).astype(f)))
+    buf.returns.copy_(torch.from_numpy((rng.standard_normal(tuple(buf.returns.shape)) * 2).astype(f)))
+    buf.actions.copy_(torch.from_numpy(rng.integers(0, A, tuple(buf.actions.shape)).astype(f)))
+    buf.action_log_probs.copy_(torch.from_numpy((-np.abs(rng.standard_normal(tuple(buf.actions.shape))) - 2).astype(f)))
+    buf.masks.copy_(torch.from_numpy((rng.random(tuple(buf.masks.shape)) > 0.15).astype(f)))
+    buf.active_masks.copy_(torch.from_numpy((rng.random(tuple(buf.masks.shape)) > 0.2).astype(f)))
+    av = (rng.random(tuple(buf.available_actions.shape)) > 0.3).astype(f)
+    np.put_along_axis(av[:T], buf.actions.cpu().numpy().astype(np.int64), 1.0, axis=-1)
+    buf.available_actions.copy_(torch.from_numpy(av))
+    oa = O.default_args(episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=2, num_mini_batch=1,
+                        use_recurrent_policy=rec, data_chunk_length=L, gain=1.0)
+    opol = O.PolicyRef(oa, D, S, A)
+    opol.actor.load_state_dict({k: v.cpu() for k, v in pol.actor.state_dict().items()})
+    opol.critic.load_state_dict({k: v.cpu() for k, v in pol.critic.state_dict().items()})
+    ob = O.BufferRef(oa, Ma, D, S, A)
+    for n in BUF_NAMES:
+        getattr(ob, n)[...] = getattr(buf, n).cpu().numpy()
+    ovn = O.ValueNormRef()
+    torch.manual_seed(13)
+    n_perm = (T * N * Ma) // L if rec else T * N * Ma
+    perms = [torch.randperm(n_perm).numpy() for _ in range(2)]
+    oinfo = O.train_ref(oa, opol, ovn, ob, perms=perms)
+    torch.manual_seed(13)
+    info = tr.train(buf)
+    for k in oinfo:
+        close(info[k], oinfo[k], 1e-4, 1e-6, k)
+    for k, v in pol.actor.state_dict().items():
+        close(v, opol.actor.state_dict()[k].numpy(), 1e-4, 6e-6, k)
+    for k, v in pol.critic.state_dict().items():
+        close(v, opol.critic.state_dict()[k].numpy(), 1e-4, 6e-6, k)

@@ -272,7 +272,10 @@ def _randomize(module, seed):
 NET_CASES = [  # D, A, relu, layer_N, feature_norm, B
     (18, 5, True, 1, True, 3072), (54, 1, True, 1, True, 3072), (18, 5, False, 1, True, 700), (54, 1, False, 1, True, 100),
     (30, 9, True, 1, True, 333), (48, 1, True, 1, True, 64), (64, 18, True, 1, False, 257), (7, 3, True, 0, True, 90),
-    (33, 32, False, 2, True, 130), (18, 5, True, 1, True, 1)]
+    (33, 32, False, 2, True, 130), (18, 5, True, 1, True, 1),
+    # wide observations (K-chunked layer 1): SMAC MMM2 shapes (BASELINE configs[3]) and the 512-wide stress config
+    (176, 18, True, 1, True, 300), (322, 1, True, 1, True, 257), (512, 5, False, 1, True, 100), (70, 3, True, 1, False, 64),
+    (130, 1, True, 0, True, 33)]
 
 
 @pytest.mark.parametrize("D,A,relu,LN,fn,B", NET_CASES)
@@ -387,6 +390,7 @@ def test_mlp_backward_vs_autograd(ops, D, A, relu, LN, fn, B):
     n_slabs = ops.mlp_backward_slabs(B)
     stride = ((P + 255) // 256) * 256 + 256
     slabs = torch.full((n_slabs, stride), float("nan"), device="cuda")
+    slabs[:, 256:256 + P] = 0.0      # contract: the caller zero-initialises its column range once (wide inputs write fewer rows of W1)
     ops.mlp_backward(params, desc, dev(x), dev(rows, torch.int32), B, dev(dout), slabs, stride, 256)
     grad = torch.zeros(stride, device="cuda")
     ops.slab_reduce(slabs[:, 256:].contiguous(), n_slabs, stride - 256, P, grad)
@@ -431,7 +435,8 @@ def test_mlp_full_size_linearity(ops):
 
 @pytest.mark.parametrize("D,S,A,relu,B,with_rows", [(18, 54, 5, True, 3072, True), (18, 54, 5, False, 500, False),
                                                     (30, 48, 9, True, 333, True), (64, 64, 18, True, 100, False),
-                                                    (18, 54, 5, True, 76800, False)])
+                                                    (18, 54, 5, True, 76800, False), (176, 322, 18, True, 700, True),
+                                                    (512, 512, 5, True, 260, False)])
 def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, with_rows):
     """mappo_actor_update / mappo_critic_update (forward + in-kernel PPO loss + backward in one launch) against
     (a) the standalone sequence mlp_forward -> ppo_loss_fwd_bwd -> mlp_backward and (b) torch autograd through
