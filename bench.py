@@ -226,6 +226,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- device time of the two phases of a step (same hipGraph path, three more iterations, HIP events) ----
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    ph = [0.0, 0.0]
+    for i in range(3):
+        ev[0].record(); runner.rollout(); ev[1].record(); runner.train(); ev[2].record()
+        torch.cuda.synchronize()
+        ph[0] += ev[0].elapsed_time(ev[1]) / 3; ph[1] += ev[1].elapsed_time(ev[2]) / 3
+    phase_ms = dict(rollout_T_steps_plus_gae=ph[0], train_ppo_epochs=ph[1])
+
     # ---- per-kernel device time: two more iterations of the SAME step, launched eagerly so that every dispatch of
     # the hot kernels carries HIP events (hipGraph replays cannot be instrumented from the host) ----
     graph_flags = (runner._use_graph, runner.trainer._use_graph)
@@ -265,7 +274,7 @@ def main():
                            num_agents=M, ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch,
                            agent_steps_per_step=per_gpu_steps * world, parallelism=f"dp{world}",
                            exact_minibatch_order=bool(args.exact_minibatch_order), hip_graph=bool(graph_flags[1])),
-               roofline=roofline, ppo_loss_roofline=loss_roof, kernels_us=kern,
+               roofline=roofline, ppo_loss_roofline=loss_roof, kernels_us=kern, phase_ms=phase_ms,
                last_train_info={k: float(v) for k, v in info.items()})
     if rank == 0:
         if world == 1 and not ns.no_cpu_baseline:

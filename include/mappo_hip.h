@@ -171,7 +171,9 @@ int mappo_critic_update(const float *params, const mappo_net_desc *desc /*host*/
                         mappo_stream_t stream);
 int mappo_update_stats(const double *actor_partials, int32_t n_actor /*workgroups that wrote them*/,
                        const double *critic_partials, int32_t n_critic, const double *mb_moments,
-                       const mappo_ppo_cfg *cfg /*host*/, double *stats /*[6]*/, mappo_stream_t stream);
+                       const mappo_ppo_cfg *cfg /*host*/, double *stats /*[6]*/,
+                       double *acc /*[>=4] running sums of stats[0..3] over the updates of one train(), or NULL*/,
+                       mappo_stream_t stream);
 
 /* ---- K9: recurrent layer (onpolicy/algorithms/utils/rnn.py:7-80: nn.GRU(64,64) with per-step h*mask + LayerNorm) ----
  * A recurrent network = trunk (mappo_mlp_features) -> GRU -> rnn.norm -> head.  Scratch between the kernels is
@@ -220,7 +222,8 @@ int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t slab_stride, 
                       float *grad /*[P] out*/, mappo_stream_t stream);
 int mappo_clip_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
                     const int64_t *seg_bounds /*host, [n_seg+1], multiples of 256*/, int32_t n_seg,
-                    const float *opt_hyper, int32_t *opt_step, float *grad_norms, void *workspace,
+                    const float *opt_hyper, int32_t *opt_step, float *grad_norms,
+                    double *norm_acc /*[n_seg] running sums of the norms, or NULL*/, void *workspace,
                     mappo_stream_t stream);
 
 /* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel carries the two hipEvent_t

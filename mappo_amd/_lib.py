@@ -54,7 +54,7 @@ SIGNATURES = {
                                      _I64, _P, _P, _P]),
     "mappo_critic_update": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _P, _P, _P, C.POINTER(PpoCfg), _P, _I64,
                                       _I64, _P, _P, _P]),
-    "mappo_update_stats": (C.c_int, [_P, _I32, _P, _I32, _P, C.POINTER(PpoCfg), _P, _P]),
+    "mappo_update_stats": (C.c_int, [_P, _I32, _P, _I32, _P, C.POINTER(PpoCfg), _P, _P, _P]),
     "mappo_mlp_features": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P]),
     "mappo_gru_scratch_floats": (_I64, [_I32, _I32]),
     "mappo_gru_forward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _I32, _U64, _U64,
@@ -67,7 +67,7 @@ SIGNATURES = {
     "mappo_trunk_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _I64, _I64, _P, _P]),
     "mappo_optim_workspace_bytes": (_I64, [_I64]),
     "mappo_slab_reduce": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),
-    "mappo_clip_adam": (C.c_int, [_P, _P, _P, _P, C.POINTER(_I64), _I32, _P, _P, _P, _P, _P]),
+    "mappo_clip_adam": (C.c_int, [_P, _P, _P, _P, C.POINTER(_I64), _I32, _P, _P, _P, _P, _P, _P]),
     "mappo_profile_arm": (C.c_int, [_I32, _P, _P]),
     "mappo_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),
 }

@@ -82,16 +82,18 @@ class R_MAPPO():
         return self._buf(name, (int(nbytes),), torch.uint8)
 
     # ---- one PPO update on rows of flat source arrays (r_mappo.py:91-164) -------------------------------------
-    def _update(self, src, rows, B, update_actor=True):
+    def _update(self, src, rows, B, update_actor=True, moments_ready=False):
         pol = self.policy
         A = pol.actor.n_actions
         lib = ops._lib.load()
         vn_state = self.value_normalizer.state if self._use_valuenorm else None
-        # denominators of the masked means + the moments ValueNorm.update needs (cal_value_loss, r_mappo.py:65)
-        ops.minibatch_moments(src["returns"], src["active"], rows, B, self._mb_moments,
-                              self._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
-        if self._dist is not None:
-            self._dist.all_reduce_sum_(self._mb_moments)
+        # denominators of the masked means + the moments ValueNorm.update needs (cal_value_loss, r_mappo.py:65);
+        # `moments_ready`: the minibatch is the whole buffer again, its sums were taken by the first epoch
+        if not moments_ready:
+            ops.minibatch_moments(src["returns"], src["active"], rows, B, self._mb_moments,
+                                  self._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
+            if self._dist is not None:
+                self._dist.all_reduce_sum_(self._mb_moments)
         if self._use_valuenorm:
             ops.valuenorm_update(vn_state, self._mb_moments, self.value_normalizer.beta)
         n_slabs = ops.mlp_backward_slabs(B)
@@ -108,7 +110,7 @@ class R_MAPPO():
                                  src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa)
             ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
                               src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc)
-            ops.update_stats(pa if update_actor else None, n_slabs, pc, n_slabs, self._mb_moments, self._cfg, self._stats)
+            ops.update_stats(pa if update_actor else None, n_slabs, pc, n_slabs, self._mb_moments, self._cfg, self._stats, self._acc)
         else:
             # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
             logits = self._buf("logits", (B, A))
@@ -120,6 +122,7 @@ class R_MAPPO():
             ops.ppo_loss_fwd_bwd(logits, values, rows, src["avail"], src["actions"], src["old_logp"], src["adv"],
                                  src["active"], src["v_old"], src["returns"], vn_state, self._mb_moments, dlogits, dvalues,
                                  self._stats, self._cfg, self._bytes("loss_ws", lib.mappo_ppo_loss_workspace_bytes(B)))
+            self._acc[:4].add_(self._stats[:4])
             if update_actor:
                 ops.mlp_backward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, dlogits, slabs, P, 0)
             ops.mlp_backward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, dvalues, slabs, P, pol.seg_bounds[1])
@@ -130,9 +133,7 @@ class R_MAPPO():
             pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
             self._actor_enabled = update_actor
         ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper,
-                      pol.opt_step, pol.grad_norms, pol.opt_workspace)
-        self._acc[:4].add_(self._stats[:4])
-        self._acc[4:].add_(pol.grad_norms)
+                      pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
 
     _actor_slabs_clean = True
     _actor_enabled = True
@@ -186,13 +187,14 @@ class R_MAPPO():
         adv = self.compute_advantages(buffer)
         src, _ = self._buffer_sources(buffer, adv)
         self._acc.zero_()
-        for _ in range(self.ppo_epoch):
-            if self.num_mini_batch == 1 and not self._exact_order:
+        whole = self.num_mini_batch == 1 and not self._exact_order
+        for epoch in range(self.ppo_epoch):
+            if whole:
                 batches = [(None, S)]                      # whole buffer in place (see module docstring)
             else:
                 batches = [(rows, rows.numel()) for rows in buffer.feed_forward_rows(self.num_mini_batch)]
             for rows, B in batches:
-                self._update(src, rows, B, update_actor)
+                self._update(src, rows, B, update_actor, moments_ready=whole and epoch > 0)
         if after_update:
             buffer.after_update()
 

@@ -1416,7 +1416,8 @@ extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc 
 // mappo_ppo_loss_fwd_bwd's `stats`)
 __global__ __launch_bounds__(256) void update_stats_kernel(const double *__restrict__ pa, const double *__restrict__ pc, int na,
                                                           int nc, const double *__restrict__ mb_moments, int use_policy_active,
-                                                          int use_value_active, double *__restrict__ stats) {
+                                                          int use_value_active, double *__restrict__ stats,
+                                                          double *__restrict__ acc) {
   __shared__ double smem[16 * 4];
   double v[4] = {0.0, 0.0, 0.0, 0.0};    // sum w*min, sum w*H, sum ratio, sum w_v*l
   for (int b = threadIdx.x; b < na; b += blockDim.x) { v[0] += pa[b * 4 + 0]; v[1] += pa[b * 4 + 1]; v[2] += pa[b * 4 + 2]; }
@@ -1432,16 +1433,17 @@ __global__ __launch_bounds__(256) void update_stats_kernel(const double *__restr
     stats[3] = v[2] / Bg;
     stats[4] = mb_moments[2];
     stats[5] = mb_moments[3];
+    if (acc) { acc[0] += stats[0]; acc[1] += stats[1]; acc[2] += stats[2]; acc[3] += stats[3]; }   // train_info sums (r_mappo.py:207-212)
   }
 }
 
 extern "C" int mappo_update_stats(const double *actor_partials, int32_t n_actor, const double *critic_partials,
                                   int32_t n_critic, const double *mb_moments, const mappo_ppo_cfg *cfg, double *stats,
-                                  mappo_stream_t stream) {
+                                  double *acc, mappo_stream_t stream) {
   MAPPO_REQUIRE(critic_partials && mb_moments && cfg && stats && n_critic > 0 && n_actor >= 0, "update_stats: bad arguments");
   hipLaunchKernelGGL(update_stats_kernel, dim3(1), dim3(256), 0, as_stream(stream), actor_partials, critic_partials,
                      actor_partials ? (int)n_actor : 0, (int)n_critic, mb_moments, cfg->use_policy_active_masks,
-                     cfg->use_value_active_masks, stats);
+                     cfg->use_value_active_masks, stats, acc);
   MAPPO_CHECK_LAUNCH("update_stats");
   return MAPPO_OK;
 }

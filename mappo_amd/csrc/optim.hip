@@ -58,7 +58,8 @@ __global__ __launch_bounds__(OPT_BLOCK) void sqnorm_partial_kernel(const float *
 // seg_ws[s*4 + {0,1,2,3}] = {clip coef, step_size = lr/(1-b1^t), sqrt(1-b2^t), enabled}
 __global__ __launch_bounds__(OPT_BLOCK) void norm_finalize_kernel(const double *__restrict__ partials, SegBounds sb,
                                                                  const float *__restrict__ hyper, int32_t *step,
-                                                                 float *__restrict__ grad_norms, float *__restrict__ seg_ws) {
+                                                                 float *__restrict__ grad_norms, float *__restrict__ seg_ws,
+                                                                 double *__restrict__ norm_acc) {
   __shared__ double smem[16];
   for (int s = 0; s < sb.n; ++s) {
     const int b0 = (int)(sb.b[s] / OPT_BLOCK), b1 = (int)(sb.b[s + 1] / OPT_BLOCK);
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(OPT_BLOCK) void norm_finalize_kernel(const double *
       const double bc1 = 1.0 - pow((double)h[1], (double)t);
       const double bc2 = 1.0 - pow((double)h[2], (double)t);
       grad_norms[s] = norm;
+      if (norm_acc) norm_acc[s] += (double)norm;      // train_info's running sum of the pre-clip norms
       seg_ws[s * 4 + 0] = coef;
       seg_ws[s * 4 + 1] = (float)((double)h[0] / (bc1 > 0.0 ? bc1 : 1.0));
       seg_ws[s * 4 + 2] = (float)sqrt(bc2 > 0.0 ? bc2 : 1.0);
@@ -123,7 +125,7 @@ extern "C" int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t sl
 
 extern "C" int mappo_clip_adam(float *params, const float *grad, float *exp_avg, float *exp_avg_sq,
                                const int64_t *seg_bounds, int32_t n_seg, const float *opt_hyper, int32_t *opt_step,
-                               float *grad_norms, void *workspace, mappo_stream_t stream) {
+                               float *grad_norms, double *norm_acc, void *workspace, mappo_stream_t stream) {
   MAPPO_REQUIRE(params && grad && exp_avg && exp_avg_sq && seg_bounds && opt_hyper && opt_step && grad_norms && workspace,
                 "clip_adam: null pointer");
   MAPPO_REQUIRE(n_seg >= 1 && n_seg <= OPT_MAX_SEG, "clip_adam: n_seg=%d", n_seg);
@@ -143,7 +145,7 @@ extern "C" int mappo_clip_adam(float *params, const float *grad, float *exp_avg,
   PROF_BEGIN(MAPPO_PROF_ADAM, st);
   hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, grad, P, partials);
   hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(OPT_BLOCK), 0, st, (const double *)partials, sb, opt_hyper,
-                     opt_step, grad_norms, seg_ws);
+                     opt_step, grad_norms, seg_ws, norm_acc);
   hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, params, grad, exp_avg, exp_avg_sq, sb, opt_hyper,
                      (const float *)seg_ws);
   PROF_END(MAPPO_PROF_ADAM, st);

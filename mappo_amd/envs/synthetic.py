@@ -13,6 +13,7 @@ from ..utils.util import Discrete
 
 class SyntheticMPEEnv:
     graph_safe = True      # step() is a fixed sequence of device ops: the runner may capture an episode into a hipGraph
+    consumes_actions = False   # the synthetic dynamics ignore the actions: the runner need not build one-hot actions
 
     def __init__(self, n_rollout_threads, num_agents=3, obs_dim=18, n_actions=5, episode_length=25, seed=1, device="cuda"):
         self.N, self.M, self.D, self.A, self.T = n_rollout_threads, num_agents, obs_dim, n_actions, episode_length

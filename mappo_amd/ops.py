@@ -190,10 +190,10 @@ def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_s
     _wide(desc, share_obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
 
 
-def update_stats(actor_partials, n_actor, critic_partials, n_critic, mb_moments, cfg, stats):
+def update_stats(actor_partials, n_actor, critic_partials, n_critic, mb_moments, cfg, stats, acc=None):
     rc = _lib.load().mappo_update_stats(_ptr(actor_partials, torch.float64, allow_none=True), int(n_actor),
                                         _ptr(critic_partials, torch.float64), int(n_critic), _ptr(mb_moments, torch.float64),
-                                        C.byref(cfg), _ptr(stats, torch.float64), _stream())
+                                        C.byref(cfg), _ptr(stats, torch.float64), _ptr(acc, torch.float64, allow_none=True), _stream())
     _lib.check(rc, "mappo_update_stats")
 
 
@@ -263,12 +263,12 @@ def optim_workspace(P, device):
     return _ws(_lib.load().mappo_optim_workspace_bytes(int(P)), device)
 
 
-def clip_adam(params, grad, exp_avg, exp_avg_sq, seg_bounds, opt_hyper, opt_step, grad_norms, workspace):
+def clip_adam(params, grad, exp_avg, exp_avg_sq, seg_bounds, opt_hyper, opt_step, grad_norms, workspace, norm_acc=None):
     n_seg = len(seg_bounds) - 1
     arr = (C.c_int64 * (n_seg + 1))(*[int(b) for b in seg_bounds])
     rc = _lib.load().mappo_clip_adam(_ptr(params), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), arr, n_seg,
                                      _ptr(opt_hyper), _ptr(opt_step, torch.int32), _ptr(grad_norms),
-                                     _ptr(workspace, torch.uint8), _stream())
+                                     _ptr(norm_acc, torch.float64, allow_none=True), _ptr(workspace, torch.uint8), _stream())
     _lib.check(rc, "mappo_clip_adam")
 
 

@@ -125,7 +125,7 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
                          vn_state if head == 2 else None, tr._mb_moments, tr._cfg, s["dxT"], s["dgiT"], s["dghnT"], slabs, P, col0, part)
         ops.gru_wgrad(net.desc, s["featT"], s["gates"], s["dgiT"], s["dghnT"], L, Nc, slabs, P, col0)
         ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
-    ops.update_stats(pa if update_actor else None, n_bwd, pc, n_bwd, tr._mb_moments, tr._cfg, tr._stats)
+    ops.update_stats(pa if update_actor else None, n_bwd, pc, n_bwd, tr._mb_moments, tr._cfg, tr._stats, tr._acc)
     ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
     if tr._dist is not None:
         tr._dist.all_reduce_sum_(pol.flat_grad)
@@ -133,9 +133,7 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
         pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
         tr._actor_enabled = update_actor
     ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper, pol.opt_step,
-                  pol.grad_norms, pol.opt_workspace)
-    tr._acc[:4].add_(tr._stats[:4])
-    tr._acc[4:].add_(pol.grad_norms)
+                  pol.grad_norms, pol.opt_workspace, norm_acc=tr._acc[4:])
 
 
 def _buffer_sources(tr, buffer, adv):

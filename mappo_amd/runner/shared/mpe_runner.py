@@ -105,12 +105,13 @@ class MPERunner(Runner):
         self.trainer.prep_rollout()
         b = self.buffer
         actions, rnn_states, rnn_states_critic = self.trainer.policy.collect_into(b, step)
-        if self._onehot is None:
-            self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
-        needs_host = getattr(self.envs, "needs_host_actions", False)
-        actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]   # np.eye(n)[actions]
-        if needs_host:
-            actions_env = _t2n(actions_env)
+        actions_env = None
+        if getattr(self.envs, "consumes_actions", True):        # synthetic envs ignore the actions: skip the one-hot
+            if self._onehot is None:
+                self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
+            actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]   # np.eye(n)[actions]
+            if getattr(self.envs, "needs_host_actions", False):
+                actions_env = _t2n(actions_env)
         return b.value_preds[step], actions, b.action_log_probs[step], rnn_states, rnn_states_critic, actions_env
 
     # mpe_runner.py:125-139
@@ -118,12 +119,12 @@ class MPERunner(Runner):
         obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic = data
         b = self.buffer
         dev = b.device
-        obs_t = torch.as_tensor(obs, dtype=torch.float32).to(dev)
-        dones_t = torch.as_tensor(dones).to(dev)
-        masks = (~dones_t).to(torch.float32).view(b.n_rollout_threads, b.num_agents, 1)
+        obs_t = obs if (torch.is_tensor(obs) and obs.device == dev) else torch.as_tensor(obs, dtype=torch.float32).to(dev)
+        dones_t = dones if (torch.is_tensor(dones) and dones.device == dev) else torch.as_tensor(dones).to(dev)
+        masks = torch.logical_not(dones_t).view(b.n_rollout_threads, b.num_agents, 1)     # bool; cast by the slot copy
         rnn_a = rnn_c = None
         if self.trainer._use_recurrent_policy or self.trainer._use_naive_recurrent:
-            keep = masks.view(b.n_rollout_threads, b.num_agents, 1, 1)
+            keep = masks.view(b.n_rollout_threads, b.num_agents, 1, 1).to(torch.float32)
             rnn_a = rnn_states.view(b.n_rollout_threads, b.num_agents, b.recurrent_N, -1) * keep
             rnn_c = rnn_states_critic.view(b.n_rollout_threads, b.num_agents, b.recurrent_N, -1) * keep
         b.insert_env(self._share_obs(obs_t), obs_t, rewards, masks, rnn_a, rnn_c)

@@ -57,7 +57,14 @@ class SharedReplayBuffer(object):
 
     # ---- slot writes (shared_buffer.py:79-166) -----------------------------------------------------------
     def _put(self, dst, src):
-        dst.copy_(to_device_f32(src, self.device).view(dst.shape), non_blocking=True)
+        """One copy kernel per slot write: device tensors (any float/bool dtype, strided or broadcast views) are copied
+        straight into the slot; host arrays are uploaded first."""
+        if torch.is_tensor(src) and src.device == dst.device:
+            if src.shape != dst.shape:
+                src = src.reshape(dst.shape) if src.numel() == dst.numel() else src.expand(dst.shape)
+            dst.copy_(src)                                   # converts dtype / gathers strides in the same kernel
+        else:
+            dst.copy_(to_device_f32(src, self.device).view(dst.shape), non_blocking=True)
 
     def insert(self, share_obs, obs, rnn_states_actor, rnn_states_critic, actions, action_log_probs, value_preds, rewards,
                masks, bad_masks=None, active_masks=None, available_actions=None):
