@@ -162,13 +162,14 @@ int mappo_actor_update(const float *params, const mappo_net_desc *desc /*host*/,
                        const float *old_logp, const float *adv, const float *active,
                        const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
                        int64_t slab_stride, int64_t slab_col0, double *partials, float *wide_ws /*or NULL*/,
+                       int32_t n_blocks /*0 = mappo_mlp_backward_slabs(B); else the grid size = slab rows written*/,
                        mappo_stream_t stream);
 int mappo_critic_update(const float *params, const mappo_net_desc *desc /*host*/, const float *share_obs,
                         const int32_t *rows, int64_t B, const float *v_old, const float *returns,
                         const float *active, const float *vn_state /*[3] after update, or NULL*/,
                         const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
                         int64_t slab_stride, int64_t slab_col0, double *partials, float *wide_ws /*or NULL*/,
-                        mappo_stream_t stream);
+                        int32_t n_blocks, mappo_stream_t stream);
 int mappo_update_stats(const double *actor_partials, int32_t n_actor /*workgroups that wrote them*/,
                        const double *critic_partials, int32_t n_critic, const double *mb_moments,
                        const mappo_ppo_cfg *cfg /*host*/, double *stats /*[6]*/,

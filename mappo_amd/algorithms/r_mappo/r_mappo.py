@@ -51,6 +51,7 @@ class R_MAPPO():
         self._exact_order = bool(getattr(args, "exact_minibatch_order", False))
         self._fused = not bool(getattr(args, "unfused_update", False))
         self._use_graph = bool(getattr(args, "use_hip_graph", True))
+        self._concurrent_update = bool(getattr(args, "concurrent_update", False))
         self._graphs = {}
 
         assert (self._use_popart and self._use_valuenorm) == False, \
@@ -105,12 +106,33 @@ class R_MAPPO():
         if self._fused:
             pa = self._buf("partials_a", (1024,), torch.float64, zero=True)
             pc = self._buf("partials_c", (1024,), torch.float64, zero=True)
-            if update_actor:
-                ops.actor_update(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, src["avail"], src["actions"],
-                                 src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa)
-            ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
-                              src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc)
-            ops.update_stats(pa if update_actor else None, n_slabs, pc, n_slabs, self._mb_moments, self._cfg, self._stats, self._acc)
+            # Each update kernel wants one workgroup per CU (its LDS footprint), so two full-size launches run one after
+            # the other.  --concurrent_update instead splits the 256 CUs between the two networks and launches them on two
+            # streams; on MI355X this measured SLOWER (train 3.08 ms vs 2.52 ms at config 2), so it is off by default.
+            na, nc = (0, 0)
+            if update_actor and self._concurrent_update:      # measured slower on MI355X (the kernels interfere): off by default
+                na, nc = self._split_grid(n_slabs, pol.actor.desc.in_dim, pol.critic.desc.in_dim, B)
+            if na:
+                cur = torch.cuda.current_stream()
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=self.device)
+                side = self._side_stream
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    ops.actor_update(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, src["avail"], src["actions"],
+                                     src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa, na)
+                ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
+                                  src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc, nc)
+                cur.wait_stream(side)
+                n_pa, n_pc = na, nc
+            else:
+                if update_actor:
+                    ops.actor_update(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, src["avail"], src["actions"],
+                                     src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa)
+                ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
+                                  src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc)
+                n_pa = n_pc = n_slabs
+            ops.update_stats(pa if update_actor else None, n_pa, pc, n_pc, self._mb_moments, self._cfg, self._stats, self._acc)
         else:
             # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
             logits = self._buf("logits", (B, A))
@@ -137,6 +159,23 @@ class R_MAPPO():
 
     _actor_slabs_clean = True
     _actor_enabled = True
+    _side_stream = None
+
+    @staticmethod
+    def _split_grid(n_slabs, d_actor, d_critic, B):
+        """(actor blocks, critic blocks) for the concurrent launch, or (0, 0) to launch one after the other.  Only worth
+        it when every CU is busy anyway (n_slabs == 256) and both networks take the narrow-input kernels."""
+        if n_slabs < 256 or d_actor > 64 or d_critic > 64:
+            return 0, 0
+        tiles = (B + 31) // 32
+        cost = lambda d: 1.0 + 0.25 * (d > 32)            # measured per-tile cost ratio (critic D=54 vs actor D=18)
+        best = None
+        for na in range(96, 161, 4):
+            nc = 256 - na
+            t = max(-(-tiles // (4 * na)) * cost(d_actor), -(-tiles // (4 * nc)) * cost(d_critic))
+            if best is None or t < best[0]:
+                best = (t, na, nc)
+        return best[1], best[2]
 
     def _buffer_sources(self, buffer, adv):
         T = buffer.episode_length

@@ -564,6 +564,7 @@ struct UpdArgs {
   NetOff off;
   LdsMap map;
   int64_t B;
+  int n_blocks;              // grid size = slab rows written (0: one workgroup per CU, capped by the tile count)
   int n_regions;             // LDS regions of P floats used for the end-of-kernel reduction (2 when they fit)
   int p_red;                 // end of the flat parameter range this launch reduces (trunk only for HEAD 3)
   int red_base;              // start of that range (b1 for wide inputs: W1 / feature-norm grads come from wide_l1_bwd_kernel)
@@ -1156,7 +1157,11 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
   const int p_span = a.p_red - a.red_base;
   a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * p_span) ? 2 : 1;
   MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * p_span, "%s: reduction buffer too small", who);
-  const int nb = mappo_mlp_backward_slabs(a.B);    // every slab the caller sized for is written: grid == that count
+  int nb = mappo_mlp_backward_slabs(a.B);          // every slab the caller sized for is written: grid == that count
+  if (a.n_blocks > 0) {                            // caller-chosen grid (actor and critic side by side on disjoint CUs)
+    MAPPO_REQUIRE(a.n_blocks <= NUM_CU, "%s: n_blocks %d > %d", who, a.n_blocks, NUM_CU);
+    nb = a.n_blocks < nb ? a.n_blocks : nb;
+  }
   dim3 grid((unsigned)nb), block(WAVE * nw);
 #define UPD2(R, L, W)                                                                                      \
   do {                                                                                                     \
@@ -1209,14 +1214,14 @@ extern "C" int mappo_actor_update(const float *params, const mappo_net_desc *des
                                   int64_t B, const float *avail, const float *actions, const float *old_logp,
                                   const float *adv, const float *active, const double *mb_moments,
                                   const mappo_ppo_cfg *cfg, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                                  double *partials, float *wide_ws, mappo_stream_t stream) {
+                                  double *partials, float *wide_ws, int32_t n_blocks, mappo_stream_t stream) {
   if (int rc = check_desc(desc, "actor_update")) return rc;
   MAPPO_REQUIRE(params && obs && actions && old_logp && adv && active && mb_moments && cfg && slabs && partials && B > 0,
                 "actor_update: bad arguments");
   UpdArgs a = {};
   a.params = params; a.x = obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
   a.desc = *desc; a.B = B; a.avail = avail; a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.active = active;
-  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg; a.wide_ws = wide_ws;
+  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg; a.wide_ws = wide_ws; a.n_blocks = n_blocks;
   return launch_update<1>(a, as_stream(stream), "actor_update");
 }
 
@@ -1224,7 +1229,7 @@ extern "C" int mappo_critic_update(const float *params, const mappo_net_desc *de
                                    const int32_t *rows, int64_t B, const float *v_old, const float *returns,
                                    const float *active, const float *vn_state, const double *mb_moments,
                                    const mappo_ppo_cfg *cfg, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                                   double *partials, float *wide_ws, mappo_stream_t stream) {
+                                   double *partials, float *wide_ws, int32_t n_blocks, mappo_stream_t stream) {
   if (int rc = check_desc(desc, "critic_update")) return rc;
   MAPPO_REQUIRE(desc->out_dim == 1, "critic_update: out_dim must be 1");
   MAPPO_REQUIRE(params && share_obs && v_old && returns && active && mb_moments && cfg && slabs && partials && B > 0,
@@ -1233,7 +1238,7 @@ extern "C" int mappo_critic_update(const float *params, const mappo_net_desc *de
   UpdArgs a = {};
   a.params = params; a.x = share_obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
   a.desc = *desc; a.B = B; a.v_old = v_old; a.returns = returns; a.active = active; a.vn_state = vn_state;
-  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg; a.wide_ws = wide_ws;
+  a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg; a.wide_ws = wide_ws; a.n_blocks = n_blocks;
   return launch_update<2>(a, as_stream(stream), "critic_update");
 }
 

@@ -169,23 +169,25 @@ def update_partials(device):
 
 
 def actor_update(params, desc, obs, rows, B, avail, actions, old_logp, adv, active, mb_moments, cfg, slabs, slab_stride,
-                 slab_col0, partials):
+                 slab_col0, partials, n_blocks=0):
     ws = wide_workspace(desc, B, obs.device)
     rc = _lib.load().mappo_actor_update(_ptr(params), C.byref(desc), _ptr(obs), _ptr(rows, torch.int32, allow_none=True), int(B),
                                         _ptr(avail, allow_none=True), _ptr(actions), _ptr(old_logp), _ptr(adv), _ptr(active),
                                         _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(slabs), int(slab_stride),
-                                        int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), _stream())
+                                        int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), int(n_blocks),
+                                        _stream())
     _lib.check(rc, "mappo_actor_update")
     _wide(desc, obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
 
 
 def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_state, mb_moments, cfg, slabs, slab_stride,
-                  slab_col0, partials):
+                  slab_col0, partials, n_blocks=0):
     ws = wide_workspace(desc, B, share_obs.device)
     rc = _lib.load().mappo_critic_update(_ptr(params), C.byref(desc), _ptr(share_obs), _ptr(rows, torch.int32, allow_none=True),
                                          int(B), _ptr(v_old), _ptr(returns), _ptr(active), _ptr(vn_state, allow_none=True),
                                          _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(slabs), int(slab_stride),
-                                         int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), _stream())
+                                         int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), int(n_blocks),
+                                         _stream())
     _lib.check(rc, "mappo_critic_update")
     _wide(desc, share_obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
 

@@ -351,3 +351,33 @@ def test_cpu_device_refused(M):
     a = make_args(M)
     with pytest.raises(MappoHipError):
         M.R_MAPPOPolicy(a, [18], [54], M.Discrete(5), device=torch.device("cpu"))
+
+
+def test_concurrent_update_launch_matches_sequential(M):
+    """BASELINE config-2 batch (76 800 samples): the split-grid two-stream launch of the actor / critic update kernels
+    gives the same update as launching them one after the other (only the slab partition of the sums differs)."""
+    T, N, Ma, D, A = 25, 1024, 3, 18, 5
+    res = []
+    for split in (True, False):
+        a = make_args(M, episode_length=T, n_rollout_threads=N, ppo_epoch=2, lr=7e-4, critic_lr=7e-4, use_hip_graph=False,
+                      concurrent_update=split)
+        torch.manual_seed(3)
+        pol = M.R_MAPPOPolicy(a, [D], [D * Ma], M.Discrete(A))
+        tr = M.R_MAPPO(a, pol)
+        if split:
+            assert tr._split_grid(256, D, D * Ma, T * N * Ma)[0] > 0
+        buf = M.SharedReplayBuffer(a, Ma, [D], [D * Ma], M.Discrete(A))
+        g = torch.Generator(device="cuda").manual_seed(7)
+        for n in ("share_obs", "obs", "rewards"):
+            getattr(buf, n).copy_(torch.randn(getattr(buf, n).shape, device="cuda", generator=g))
+        buf.value_preds.copy_(torch.randn(buf.value_preds.shape, device="cuda", generator=g) * 0.3)
+        buf.returns.copy_(torch.randn(buf.returns.shape, device="cuda", generator=g) * 2)
+        buf.actions.copy_(torch.randint(0, A, buf.actions.shape, device="cuda", generator=g).float())
+        buf.action_log_probs.copy_(-torch.rand(buf.actions.shape, device="cuda", generator=g) - 1.2)
+        buf.active_masks.copy_((torch.rand(buf.masks.shape, device="cuda", generator=g) > 0.2).float())
+        info = tr.train(buf)
+        res.append((info, pol.flat_params.clone(), pol.flat_grad.clone()))
+    for k in res[0][0]:
+        close(res[0][0][k], res[1][0][k], 1e-5, 1e-7, k)
+    close(res[0][2], res[1][2], 1e-4, 1e-7, "last gradient")
+    close(res[0][1], res[1][1], 1e-5, 2e-6, "parameters")
