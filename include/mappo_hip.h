@@ -61,6 +61,15 @@ typedef struct {
 
 int64_t mappo_net_param_count(const mappo_net_desc *desc /*host*/);
 
+/* ---- K1: MPE rollout insert (mpe_runner.py:125-139, shared_buffer.py:96-112) in one launch -----------------------
+ * Sources may be strided / broadcast views (strides in elements); destinations are the contiguous buffer slots
+ * obs[step+1], share_obs[step+1], rewards[step], masks[step+1].  centralized != 0 builds share_obs as the thread's
+ * concatenated agent observations repeated per agent (use_centralized_V). */
+int mappo_insert_mpe(const float *obs, int64_t obs_stride_n, int64_t obs_stride_m, const float *rewards,
+                     int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones /*bool bytes*/,
+                     int64_t done_stride_n, int64_t done_stride_m, float *obs_dst, float *share_dst, float *rew_dst,
+                     float *mask_dst, int32_t N, int32_t M, int32_t D, int32_t centralized, mappo_stream_t stream);
+
 /* ---- K2: compute_returns (shared_buffer.py:168-224), all four flag branches ------------------------
  * Segmented affine-map scan over T: one wavefront per (64 series x time segment), segment composites
  * combined through LDS.  Writes value_preds[T] <- next_value (GAE branches) or returns[T] <- next_value

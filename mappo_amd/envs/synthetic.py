@@ -23,6 +23,7 @@ class SyntheticMPEEnv:
         self.share_observation_space = [[obs_dim * num_agents] for _ in range(num_agents)]
         self.action_space = [Discrete(n_actions) for _ in range(num_agents)]
         self.t = 0
+        self._pool = None
         self._done_true = torch.ones(self.N, self.M, dtype=torch.bool, device=self.device)
         self._done_false = torch.zeros(self.N, self.M, dtype=torch.bool, device=self.device)
         with torch.cuda.device(self.device):
@@ -33,8 +34,11 @@ class SyntheticMPEEnv:
         return torch.randn(self.N, self.M, self.D, device=self.device)
 
     def step(self, actions_env=None):
+        i = self.t % self.T
+        if i == 0:          # one generator launch per episode: T x (obs + shared reward); episode-aligned, so a captured
+            self._pool = torch.randn(self.T, self.N, self.M * self.D + 1, device=self.device)   # episode graph redraws it
         self.t += 1
-        blk = torch.randn(self.N, self.M * self.D + 1, device=self.device)      # one launch: obs + shared reward
+        blk = self._pool[i]
         obs = blk[:, :self.M * self.D].view(self.N, self.M, self.D)
         rewards = blk[:, self.M * self.D:].view(self.N, 1, 1).expand(self.N, self.M, 1)
         dones = self._done_true if (self.t % self.T == 0) else self._done_false   # fixed per step index of an episode

@@ -41,6 +41,20 @@ def net_param_count(desc):
     return int(_lib.load().mappo_net_param_count(C.byref(desc)))
 
 
+# ---- K1 -------------------------------------------------------------------------------------------
+def insert_mpe(obs, rewards, dones, obs_dst, share_dst, rew_dst, mask_dst, centralized):
+    """obs [N, M, D] (innermost stride 1), rewards [N, M(, 1)], dones [N, M] bool — device tensors, arbitrary outer strides."""
+    N, M, D = obs.shape
+    if rewards.dim() == 3:
+        rewards = rewards[..., 0]
+    assert obs.is_cuda and obs.dtype == torch.float32 and obs.stride(2) == 1 and rewards.dtype == torch.float32 and dones.dtype == torch.bool
+    rc = _lib.load().mappo_insert_mpe(C.c_void_p(obs.data_ptr()), obs.stride(0), obs.stride(1), C.c_void_p(rewards.data_ptr()),
+                                      rewards.stride(0), rewards.stride(1), C.c_void_p(dones.data_ptr()), dones.stride(0),
+                                      dones.stride(1), _ptr(obs_dst), _ptr(share_dst), _ptr(rew_dst), _ptr(mask_dst), int(N), int(M),
+                                      int(D), int(bool(centralized)), _stream())
+    _lib.check(rc, "mappo_insert_mpe")
+
+
 # ---- K2 -------------------------------------------------------------------------------------------
 def gae_scan(rewards, value_preds, next_value, masks, bad_masks, returns, vn_state, gamma, gae_lambda,
              use_gae=True, use_proper_time_limits=False):

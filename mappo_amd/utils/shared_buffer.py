@@ -107,6 +107,20 @@ class SharedReplayBuffer(object):
             self._put(self.available_actions[s + 1], available_actions)
         self.step = (s + 1) % self.episode_length
 
+    def insert_mpe_fused(self, obs, rewards, dones, centralized):
+        """MPE rollout insert as ONE kernel (mappo_insert_mpe): obs / share_obs -> slot step+1, rewards -> slot step,
+        masks = 1 - done -> slot step+1.  Returns False (nothing written) when the inputs are not device tensors of the
+        expected dtypes, so the caller can fall back to the generic slot copies."""
+        ok = (torch.is_tensor(obs) and torch.is_tensor(rewards) and torch.is_tensor(dones) and obs.device == self.device
+              and obs.dtype == torch.float32 and obs.dim() == 3 and obs.stride(2) == 1 and rewards.device == self.device
+              and rewards.dtype == torch.float32 and dones.device == self.device and dones.dtype == torch.bool and dones.dim() == 2)
+        if not ok:
+            return False
+        s = self.step
+        ops.insert_mpe(obs, rewards, dones, self.obs[s + 1], self.share_obs[s + 1], self.rewards[s], self.masks[s + 1], centralized)
+        self.step = (s + 1) % self.episode_length
+        return True
+
     def chooseinsert(self, share_obs, obs, rnn_states, rnn_states_critic, actions, action_log_probs, value_preds, rewards,
                      masks, bad_masks=None, active_masks=None, available_actions=None):
         """Turn-based (Hanabi) insert, shared_buffer.py:114-147: obs/share_obs/active/avail go to slot `step`."""

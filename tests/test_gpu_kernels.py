@@ -567,3 +567,23 @@ def test_ops_reject_cpu_tensors(ops):
     from mappo_amd._lib import MappoHipError
     with pytest.raises(MappoHipError):
         ops.adv_normalize(torch.zeros(8), torch.zeros(3, dtype=torch.float64))
+
+
+@pytest.mark.parametrize("centralized", [True, False])
+def test_insert_mpe_kernel(ops, centralized):
+    """K1: one launch == the four slot writes of mpe_runner.insert / SharedReplayBuffer.insert, bit for bit, with strided
+    (slice of a wider block) obs, broadcast rewards and bool dones."""
+    N, M, D = 37, 3, 18
+    g = torch.Generator(device="cuda").manual_seed(0)
+    blk = torch.randn(N, M * D + 1, device="cuda", generator=g)
+    obs = blk[:, :M * D].view(N, M, D)
+    rew = blk[:, M * D:].view(N, 1, 1).expand(N, M, 1)
+    dones = torch.rand(N, M, device="cuda", generator=g) > 0.5
+    S = M * D if centralized else D
+    od, sd, rd, md = (torch.full(s, float("nan"), device="cuda") for s in ((N, M, D), (N, M, S), (N, M, 1), (N, M, 1)))
+    ops.insert_mpe(obs, rew, dones, od, sd, rd, md, centralized)
+    share_ref = obs.reshape(N, 1, -1).expand(N, M, -1) if centralized else obs
+    np.testing.assert_array_equal(od.cpu().numpy(), obs.cpu().numpy())
+    np.testing.assert_array_equal(sd.cpu().numpy(), share_ref.cpu().numpy())
+    np.testing.assert_array_equal(rd.cpu().numpy(), rew.cpu().numpy())
+    np.testing.assert_array_equal(md.cpu().numpy(), (~dones).float().view(N, M, 1).cpu().numpy())
