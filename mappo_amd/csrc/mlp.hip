@@ -206,7 +206,9 @@ __device__ __forceinline__ void prefetch_rows(RowPrefetch<WIDE> &pf, const float
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     pf.v[j] = 0.f;
+#ifndef EXP_NO_PREFETCH
     if (ok && 2 * j + half < D) pf.v[j] = src[2 * j];
+#endif
   }
 }
 
@@ -595,10 +597,14 @@ __device__ __forceinline__ void regs_to_tile(float *tile, const f32x16 (&v)[2], 
 }
 
 // LayerNorm + activation backward in the accumulator layout.
-//   in : dH = d/d(h) with h = xhat*gamma + beta the LayerNorm output; `tile` holds xhat (it is consumed: the
-//        tile is reused as scratch for the row sums and finally receives dz)
-//   out: dH <- d/d(z) (pre-activation), also written to `tile`;  gG/gB (lane = feature) += LN weight/bias grads
-template <bool RELU>
+//   in : dH = d/d(h) with h = xhat*gamma + beta the LayerNorm output; `tile` holds xhat
+//   out: dH <- d/d(z) (pre-activation), also written over `tile` (each lane rewrites exactly the words it read)
+// AFFINE = false (every LayerNorm that feeds a weight matrix of this kernel): the LayerNorm weight/bias gradients
+// are NOT accumulated here — they follow from the raw products G = dz_next . xhat^T the dW MFMAs accumulate anyway
+// (d gamma[k] = sum_f W_next[f][k] G[f][k], d beta[k] = sum_f W_next[f][k] db_next[f]; see the epilogue).
+// AFFINE = true (HEAD 3: the gradient arrives at the trunk output, no weight matrix behind it): gG/gB (lane =
+// feature) += sum_s dy*xhat, sum_s dy through two transposed row sums.
+template <bool RELU, bool AFFINE>
 __device__ __forceinline__ void ln_act_backward(f32x16 (&dH)[2], float *tile, float mean, float rstd, uint32_t pos,
                                                 const float *sG, float &gG, float &gB, int lane, int l31, int half) {
   f32x16 xh[2];
@@ -606,13 +612,20 @@ __device__ __forceinline__ void ln_act_backward(f32x16 (&dH)[2], float *tile, fl
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) xh[t][r] = tile[(32 * t + ROWMAP(r, half)) * TP + l31];
-  wave_lds_sync();
-  // dbeta[f] = sum_s dy
-  regs_to_tile(tile, dH, l31, half);
-  wave_lds_sync();
-  gB += tile_row_sum(tile, lane);
-  wave_lds_sync();
-  // dgamma[f] = sum_s dy * xhat ;  dxhat = dy * gamma
+  if (AFFINE) {
+    wave_lds_sync();
+    regs_to_tile(tile, dH, l31, half);
+    wave_lds_sync();
+    gB += tile_row_sum(tile, lane);
+    wave_lds_sync();
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tile[(32 * t + ROWMAP(r, half)) * TP + l31] = dH[t][r] * xh[t][r];
+    wave_lds_sync();
+    gG += tile_row_sum(tile, lane);
+    wave_lds_sync();
+  }
   float m1 = 0.f, m2 = 0.f;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -623,16 +636,12 @@ __device__ __forceinline__ void ln_act_backward(f32x16 (&dH)[2], float *tile, fl
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int r = 4 * q + c;
-        tile[(32 * t + ROWMAP(r, half)) * TP + l31] = dH[t][r] * xh[t][r];
         const float dxh = dH[t][r] * gq[c];
         dH[t][r] = dxh;
         m1 += dxh;
         m2 += dxh * xh[t][r];
       }
     }
-  wave_lds_sync();
-  gG += tile_row_sum(tile, lane);
-  wave_lds_sync();
   m1 = xhalf_sum(m1) * (1.f / HID);
   m2 = xhalf_sum(m2) * (1.f / HID);
   const float inv_rstd = 1.0f / rstd;
@@ -709,8 +718,11 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 
   // ---- gradient accumulators (registers, live across the tile loop) ----
   f32x16 gWh[2], gW2[LN > 0 ? LN : 1][2][2], gW1[2][2];
-  float gBh = 0.f, gFnW = 0.f, gFnB = 0.f;
-  float gB[LN + 1], gLnW[LN + 1], gLnB[LN + 1];
+  // raw products: gW*[f][k] = sum_s dz[f][s] * xhat_in[k][s] (LayerNorm affine of the input NOT applied), gB = sum_s dz.
+  // The epilogue turns them into weight, LayerNorm-affine and feature-norm gradients.
+  float gBh = 0.f;
+  float gB[LN + 1];
+  float gLnW = 0.f, gLnB = 0.f;          // HEAD 3 only: affine of the last LayerNorm (the gradient arrives behind it)
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -725,7 +737,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
       }
   }
 #pragma unroll
-  for (int l = 0; l <= LN; ++l) { gB[l] = 0.f; gLnW[l] = 0.f; gLnB[l] = 0.f; }
+  for (int l = 0; l <= LN; ++l) gB[l] = 0.f;
 
   for (int64_t tb = blockIdx.x; tb < n_btiles; tb += gridDim.x) {
     const int64_t tile = tb * n_waves + wave;
@@ -789,18 +801,16 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     wave_lds_sync();
     STAMP(3);   // head forward + loss
 
-    // ---- (A) head weight / bias gradients:  dWh[a][f] += sum_s dz[s][a] * h_last[f][s] ----
+    // ---- (A) raw head products:  gWh[a][f] += sum_s dz[s][a] * xhat_last[f][s] ----
     if (HEAD != 3) {
-      const float *sG = lds + ln_w_of<LN>(m, LN), *sBt = lds + ln_b_of<LN>(m, LN);
-      const float g0 = sG[l31], c0 = sBt[l31], g1 = sG[32 + l31], c1 = sBt[32 + l31];
       float bsum = 0.f;
 #pragma unroll 2
       for (int ss = 0; ss < TS / 2; ++ss) {
         const int s = 2 * ss + half;
         const float av = (l31 < A) ? tZ[s * TP + l31] : 0.f;
         bsum += av;
-        gWh[0] = mfma(av, tLast[l31 * TP + s] * g0 + c0, gWh[0]);
-        gWh[1] = mfma(av, tLast[(32 + l31) * TP + s] * g1 + c1, gWh[1]);
+        gWh[0] = mfma(av, tLast[l31 * TP + s], gWh[0]);
+        gWh[1] = mfma(av, tLast[(32 + l31) * TP + s], gWh[1]);
       }
       gBh += xhalf_sum(bsum);
     }
@@ -831,18 +841,19 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     for (int l = LN; l >= 1; --l) {
       float *tCur = tH + l * HID * TP;          // xhat of this layer's LayerNorm -> scratch -> dz
       float *tPrev = tH + (l - 1) * HID * TP;   // xhat of the layer's input
-      ln_act_backward<RELU>(dH, tCur, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW[l], gLnB[l], lane, l31, half);
+      if (HEAD == 3 && l == LN)
+        ln_act_backward<RELU, true>(dH, tCur, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW, gLnB, lane, l31, half);
+      else
+        ln_act_backward<RELU, false>(dH, tCur, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW, gLnB, lane, l31, half);
       gB[l] += tile_row_sum(tCur, lane);
       STAMP(5);   // LN + act backward (hidden)
-      // dW2[f_out][k_in] += sum_s dz[f_out][s] * h_prev[k_in][s]
+      // gW2[f_out][k_in] += sum_s dz[f_out][s] * xhat_prev[k_in][s]
       {
-        const float *sG = lds + ln_w_of<LN>(m, l - 1), *sBt = lds + ln_b_of<LN>(m, l - 1);
-        const float g0 = sG[l31], c0 = sBt[l31], g1 = sG[32 + l31], c1 = sBt[32 + l31];
 #pragma unroll 2
         for (int ss = 0; ss < TS / 2; ++ss) {
           const int s = 2 * ss + half;
           const float a0 = tCur[l31 * TP + s], a1 = tCur[(32 + l31) * TP + s];
-          const float b0 = tPrev[l31 * TP + s] * g0 + c0, b1 = tPrev[(32 + l31) * TP + s] * g1 + c1;
+          const float b0 = tPrev[l31 * TP + s], b1 = tPrev[(32 + l31) * TP + s];
           gW2[l - 1][0][0] = mfma(a0, b0, gW2[l - 1][0][0]);
           gW2[l - 1][0][1] = mfma(a0, b1, gW2[l - 1][0][1]);
           gW2[l - 1][1][0] = mfma(a1, b0, gW2[l - 1][1][0]);
@@ -871,7 +882,10 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     // ---- layer 1 ----
     {
       float *tCur = tH;
-      ln_act_backward<RELU>(dH, tCur, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW[0], gLnB[0], lane, l31, half);
+      if (HEAD == 3 && LN == 0)
+        ln_act_backward<RELU, true>(dH, tCur, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW, gLnB, lane, l31, half);
+      else
+        ln_act_backward<RELU, false>(dH, tCur, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW, gLnB, lane, l31, half);
       gB[0] += tile_row_sum(tCur, lane);
       STAMP(8);   // LN + act backward (layer 1)
       if (XWIDE) {
@@ -888,64 +902,28 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         wave_lds_sync();
         continue;
       }
-      // dW1[f_out][k] += sum_s dz1[f_out][s] * xn[k][s],  xn = xhat0 * gamma0 + beta0
+      // gW1[f_out][k] += sum_s dz1[f_out][s] * xhat0[k][s]   (raw input rows when feature norm is off).  No dX pass:
+      // the feature-norm gradients follow from gW1 and W1 in the epilogue.
       {
         const int k0 = l31, k1 = 32 + l31;
         const bool v0 = k0 < Dp, v1 = k1 < Dp;
-        const float g0 = v0 ? lds[m.fn_w + k0] : 0.f, c0 = v0 ? lds[m.fn_b + k0] : 0.f;
-        const float g1 = v1 ? lds[m.fn_w + k1] : 0.f, c1 = v1 ? lds[m.fn_b + k1] : 0.f;
 #pragma unroll 2
         for (int ss = 0; ss < TS / 2; ++ss) {
           const int s = 2 * ss + half;
           const float a0 = tCur[l31 * TP + s], a1 = tCur[(32 + l31) * TP + s];
-          const float b0 = v0 ? tX[k0 * TP + s] * g0 + c0 : 0.f;
+          const float b0 = v0 ? tX[k0 * TP + s] : 0.f;
           gW1[0][0] = mfma(a0, b0, gW1[0][0]);
           gW1[1][0] = mfma(a1, b0, gW1[1][0]);
           if (wide) {
-            const float b1 = v1 ? tX[k1 * TP + s] * g1 + c1 : 0.f;
+            const float b1 = v1 ? tX[k1 * TP + s] : 0.f;
             gW1[0][1] = mfma(a0, b1, gW1[0][1]);
             gW1[1][1] = mfma(a1, b1, gW1[1][1]);
           }
         }
       }
       STAMP(9);   // dW1
-      // feature-norm gradients: dxn = W1^T . dz1 ; dgamma0[k] = sum_s dxn*xhat0 ; dbeta0[k] = sum_s dxn
-      if (p.desc.use_feature_norm) {
-        f32x16 dX[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dX[t][r] = 0.f;
-        const float *sW = lds + m.w1;
-        const int k0 = l31, k1 = 32 + l31;
-#pragma unroll 2
-        for (int kk = 0; kk < HID / 2; ++kk) {
-          const int fo = 2 * kk + half;
-          const float b = tCur[fo * TP + l31];
-          const float a0 = (k0 < Dp) ? sW[k0 * WP + fo] : 0.f;
-          dX[0] = mfma(a0, b, dX[0]);
-          if (wide) {
-            const float a1 = (k1 < Dp) ? sW[k1 * WP + fo] : 0.f;
-            dX[1] = mfma(a1, b, dX[1]);
-          }
-        }
-        wave_lds_sync();
-        regs_to_tile(tCur, dX, l31, half);     // dxn tile [k][s]
-        wave_lds_sync();
-        if (lane < D) {
-          float sb = 0.f, sg = 0.f;
-#pragma unroll 8
-          for (int j = 0; j < TS; ++j) {
-            const float dx = tCur[lane * TP + j];
-            sb += dx;
-            sg += dx * tX[lane * TP + j];
-          }
-          gFnB += sb;
-          gFnW += sg;
-        }
-      }
       wave_lds_sync();
-      STAMP(10);  // dX + feature-norm grads
+      STAMP(10);
     }
   }
   STAMP(11);    // (loop exit)
@@ -998,38 +976,103 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         for (int r = 0; r < 16; ++r) { const int a = ROWMAP(r, half); if (a < A) red[o.wh + a * HID + 32 * tj + l31] = old[r] + gWh[tj][r]; }
       }
       {
-        float vals[3 * (LN + 1) + 3]; int idx[3 * (LN + 1) + 3]; bool ok[3 * (LN + 1) + 3];
+        constexpr int NVAL = LN + 4;
+        float vals[NVAL]; int idx[NVAL]; bool ok[NVAL];
         int n = 0;
         vals[n] = gB[0]; idx[n] = o.b1 + lane; ok[n++] = true;
-        vals[n] = gLnW[0]; idx[n] = o.ln1_w + lane; ok[n++] = true;
-        vals[n] = gLnB[0]; idx[n] = o.ln1_b + lane; ok[n++] = true;
 #pragma unroll
-        for (int l = 0; l < LN; ++l) {
-          vals[n] = gB[l + 1]; idx[n] = o.b2[l] + lane; ok[n++] = true;
-          vals[n] = gLnW[l + 1]; idx[n] = o.ln2_w[l] + lane; ok[n++] = true;
-          vals[n] = gLnB[l + 1]; idx[n] = o.ln2_b[l] + lane; ok[n++] = true;
-        }
+        for (int l = 0; l < LN; ++l) { vals[n] = gB[l + 1]; idx[n] = o.b2[l] + lane; ok[n++] = true; }
         vals[n] = gBh; idx[n] = (HEAD != 3) ? o.bh + l31 : 0; ok[n++] = (HEAD != 3 && half == 0 && l31 < A);
-        const bool fn = !XWIDE && p.desc.use_feature_norm && lane < D;
-        vals[n] = gFnW; idx[n] = o.fn_w + lane; ok[n++] = fn;
-        vals[n] = gFnB; idx[n] = o.fn_b + lane; ok[n++] = fn;
-        float old[3 * (LN + 1) + 3];
+        const int lw = (LN == 0) ? o.ln1_w : o.ln2_w[LN > 0 ? LN - 1 : 0], lb = (LN == 0) ? o.ln1_b : o.ln2_b[LN > 0 ? LN - 1 : 0];
+        vals[n] = gLnW; idx[n] = lw + lane; ok[n++] = (HEAD == 3);
+        vals[n] = gLnB; idx[n] = lb + lane; ok[n++] = (HEAD == 3);
+        float old[NVAL];
 #pragma unroll
-        for (int i = 0; i < 3 * (LN + 1) + 3; ++i) old[i] = (!first && ok[i]) ? red[idx[i]] : 0.f;
+        for (int i = 0; i < NVAL; ++i) old[i] = (!first && ok[i]) ? red[idx[i]] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 3 * (LN + 1) + 3; ++i) if (ok[i]) red[idx[i]] = old[i] + vals[i];
+        for (int i = 0; i < NVAL; ++i) if (ok[i]) red[idx[i]] = old[i] + vals[i];
       }
     }
     __syncthreads();
   }
-  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0 + rb;
-  const float *redv = red0 + rb;
-  if (n_reg > 1) {
-    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = redv[e] + redv[P + e];
-  } else {
-    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = redv[e];
+  STAMP(12);    // block reduction through LDS
+
+  // ---- epilogue: raw products -> gradients, written straight to this workgroup's slab -------------------------------
+  // With h_in = xhat_in*gamma + beta feeding  z = W h_in + b,  G[f][k] = sum_s dz[f][s] xhat_in[k][s],  db[f] = sum_s dz[f][s]:
+  //   dW[f][k] = gamma[k] G[f][k] + beta[k] db[f]      d gamma[k] = sum_f W[f][k] G[f][k]      d beta[k] = sum_f W[f][k] db[f]
+  // (all linear in G and db, so they commute with the cross-workgroup slab sum that follows).
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;     // absolute flat offsets below
+  auto R = [&](int e) -> float { return n_reg > 1 ? red0[e] + red0[P + e] : red0[e]; };
+  const int tid = threadIdx.x, kk = tid & 63, f0 = tid >> 6, fstep = blockDim.x >> 6;
+  const bool fnorm = p.desc.use_feature_norm != 0;
+  // weight matrices (thread = column k, rows strided)
+  if (!XWIDE && kk < D) {
+    const float g = fnorm ? lds[m.fn_w + kk] : 1.f, bt = fnorm ? lds[m.fn_b + kk] : 0.f;
+    for (int f = f0; f < HID; f += fstep) slab[o.w1 + f * D + kk] = g * R(o.w1 + f * D + kk) + bt * R(o.b1 + f);
   }
-  STAMP(12);    // block reduction + slab write
+#pragma unroll
+  for (int l = 0; l < LN; ++l) {
+    const float g = lds[ln_w_of<LN>(m, l) + kk], bt = lds[ln_b_of<LN>(m, l) + kk];
+    for (int f = f0; f < HID; f += fstep) slab[o.w2[l] + f * HID + kk] = g * R(o.w2[l] + f * HID + kk) + bt * R(o.b2[l] + f);
+  }
+  if (HEAD != 3) {
+    const float g = lds[ln_w_of<LN>(m, LN) + kk], bt = lds[ln_b_of<LN>(m, LN) + kk];
+    for (int a = f0; a < A; a += fstep) slab[o.wh + a * HID + kk] = g * R(o.wh + a * HID + kk) + bt * R(o.bh + a);
+  }
+  // vectors, one 64-wide group per wave at a time (wave-uniform branches, compile-time offsets; lane = k):
+  // biases as accumulated; LayerNorm / feature-norm affine from the consumer's weights and raw products
+  {
+    int g = 0;                                            // running group index (compile-time after unrolling)
+    auto mine = [&](int gi) { return (gi % n_waves) == wave; };
+    if (mine(g)) slab[o.b1 + lane] = R(o.b1 + lane);
+    ++g;
+#pragma unroll
+    for (int l = 0; l < LN; ++l) {
+      if (mine(g)) slab[o.b2[l] + lane] = R(o.b2[l] + lane);
+      ++g;
+    }
+#pragma unroll
+    for (int j = 0; j <= LN; ++j) {                       // LayerNorm j (tile tH[j]) feeds hidden layer j, or the head
+      const int ow = (j == 0) ? o.ln1_w : o.ln2_w[j > 0 ? j - 1 : 0], ob = (j == 0) ? o.ln1_b : o.ln2_b[j > 0 ? j - 1 : 0];
+      if (j < LN) {
+        if (mine(g)) {
+          const float *sW = lds + m.w2[j < LN ? j : 0];
+          const int gw = o.w2[j < LN ? j : 0], gb = o.b2[j < LN ? j : 0];
+          float dg = 0.f, db = 0.f;
+#pragma unroll 4
+          for (int f = 0; f < HID; ++f) { const float w = sW[lane * WP + f]; dg += w * R(gw + f * HID + lane); db += w * R(gb + f); }
+          slab[ow + lane] = dg;
+          slab[ob + lane] = db;
+        }
+      } else if (HEAD != 3) {
+        if (mine(g)) {
+          const float *sW = lds + m.wh;
+          float dg = 0.f, db = 0.f;
+          for (int a = 0; a < A; ++a) { const float w = sW[lane * HP + a]; dg += w * R(o.wh + a * HID + lane); db += w * R(o.bh + a); }
+          slab[ow + lane] = dg;
+          slab[ob + lane] = db;
+        }
+      } else {                                            // HEAD 3: accumulated directly by ln_act_backward<.., true>
+        if (mine(g)) { slab[ow + lane] = R(ow + lane); slab[ob + lane] = R(ob + lane); }
+      }
+      ++g;
+    }
+    if (fnorm && !XWIDE) {                                // feature norm feeds layer 1
+      if (mine(g) && lane < D) {
+        const float *sW = lds + m.w1;
+        float dg = 0.f, db = 0.f;
+#pragma unroll 4
+        for (int f = 0; f < HID; ++f) { const float w = sW[lane * WP + f]; dg += w * R(o.w1 + f * D + lane); db += w * R(o.b1 + f); }
+        slab[o.fn_w + lane] = dg;
+        slab[o.fn_b + lane] = db;
+      }
+      ++g;
+    }
+    if (HEAD != 3) {
+      if (mine(g) && lane < A) slab[o.bh + lane] = R(o.bh + lane);
+    }
+  }
+  STAMP(13);    // slab write
   STAMP_FLUSH();
 }
 

@@ -6,14 +6,14 @@ sys.path.insert(0, '.')
 ROOT = os.getcwd()
 out = os.path.join(ROOT, 'gpurun_out', 'libmappo_hip_stamps.so')
 srcs = [os.path.join(ROOT, 'mappo_amd', 'csrc', f) for f in sorted(os.listdir(os.path.join(ROOT, 'mappo_amd', 'csrc'))) if f.endswith('.hip')]
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DMLP_STAMPS', '-w', '-o', out] + srcs)
+subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DMLP_STAMPS', '-w'] + os.environ.get('STAMP_FLAGS', '').split() + [ '-o', out] + srcs)
 from mappo_amd import _lib
 _lib.LIB_PATH = out
 _lib.SIGNATURES['mappo_debug_set_stamps'] = (ctypes.c_int, [ctypes.c_void_p])
 from mappo_amd import ops
 lib = _lib.load()
 NAMES = ['staging', 'commit+prefetch+featnorm', 'trunk fwd', 'head fwd + loss', 'head grads A,B', 'LNbwd hidden', 'dW2', 'dH hidden',
-         'LNbwd L1', 'dW1', 'dX + fn grads', 'loop exit', 'block reduce + slab', '', '', '']
+         'LNbwd L1', 'dW1', 'dX + fn grads', 'loop exit', 'block reduce (LDS)', 'slab write', '', '']
 class A_: pass
 a = A_(); a.clip_param=0.2; a.entropy_coef=0.01; a.value_loss_coef=1.0; a.huber_delta=10.0; a.use_huber_loss=True; a.use_clipped_value_loss=True; a.use_policy_active_masks=True; a.use_value_active_masks=True; a.use_valuenorm=True
 cfg = ops.ppo_cfg(a)
