@@ -48,6 +48,7 @@ extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
 struct LdsMap {
   int w1, w2[MAPPO_MAX_LAYER_N], wh;
   int fn_w, fn_b, b1, ln1_w, ln1_b, b2[MAPPO_MAX_LAYER_N], ln2_w[MAPPO_MAX_LAYER_N], ln2_b[MAPPO_MAX_LAYER_N], bh;
+  int scratch;       // n_waves x 64 floats: per-wave vector scratch of the update kernel's epilogue
   int tiles, x_rows, wave_stride, total;
   int fn_size;       // floats reserved per feature-norm vector (64, or in_dim rounded up to 64 for wide inputs)
 };
@@ -69,6 +70,7 @@ __host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves) 
     if (l < d.layer_N) { m.b2[l] = p; p += HID; m.ln2_w[l] = p; p += HID; m.ln2_b[l] = p; p += HID; }
   }
   m.bh = p; p += 32;
+  m.scratch = p; p += n_waves * HID;
   m.tiles = p;
   m.x_rows = Dp;
   m.wave_stride = al4((Dp + (d.layer_N + 1) * HID + TS) * TP);
@@ -683,6 +685,46 @@ __device__ __forceinline__ void prefetch_loss(LossPrefetch &lp, const UpdArgs &p
   }
 }
 
+// Epilogue of the update kernel, per wave and in registers: raw products -> gradient partials.
+// With h_in = xhat_in*gamma + beta feeding z = W h_in + b,  G[f][k] = sum_s dz[f][s] xhat_in[k][s],  db[f] = sum_s dz[f][s]:
+//   dW[f][k] = gamma[k] G[f][k] + beta[k] db[f]      d gamma[k] = sum_f W[f][k] G[f][k]      d beta[k] = sum_f W[f][k] db[f]
+// (linear in G and db, so applying them to each wave's partial sums commutes with the reductions that follow).
+// g[ti][tj]: accumulator tiles, rows f = 32 ti + ROWMAP(r, half), columns k = 32 tj + l31.  dbv: db, lane = f.
+// sW: the consumer's weights in LDS, k-major (sW[k*wstride + f]).  On return g holds dW, dgam/dbet (lane = k) the affine grads.
+template <int NTI>
+__device__ __forceinline__ void raw_to_grad(f32x16 (&g)[NTI][2], float dbv, float *scr, const float *sW, int wstride, const float *sG,
+                                            const float *sBt, int K, bool two_k_tiles, int lane, int l31, int half, float &dgam,
+                                            float &dbet) {
+  scr[lane] = dbv;
+  wave_lds_sync();
+  float dg[2] = {0.f, 0.f}, dt[2] = {0.f, 0.f};
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj) {
+    if (tj == 1 && !two_k_tiles) break;
+    const int k = 32 * tj + l31;
+    const bool valid = k < K;
+    const int kc = valid ? k : 0;
+    const float gam = valid ? sG[kc] : 0.f, bet = valid ? sBt[kc] : 0.f;
+#pragma unroll
+    for (int ti = 0; ti < NTI; ++ti) {
+      float w[16], d[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { const int f = 32 * ti + ROWMAP(r, half); w[r] = sW[kc * wstride + f]; d[r] = scr[f]; }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float wv = valid ? w[r] : 0.f;
+        dg[tj] += wv * g[ti][tj][r];
+        dt[tj] += wv * d[r];
+        g[ti][tj][r] = gam * g[ti][tj][r] + bet * d[r];
+      }
+    }
+  }
+  const float a0 = xhalf_sum(dg[0]), a1 = xhalf_sum(dg[1]), b0 = xhalf_sum(dt[0]), b1 = xhalf_sum(dt[1]);
+  dgam = half ? a1 : a0;
+  dbet = half ? b1 : b0;
+  wave_lds_sync();
+}
+
 template <bool RELU, int LN, int HEAD, int XW>
 __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   extern __shared__ __align__(16) float lds[];
@@ -717,7 +759,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
   double lacc[4] = {0.0, 0.0, 0.0, 0.0};   // actor: sum w*min(s1,s2), sum w*H, sum ratio | critic: sum w_v*l
 
   // ---- gradient accumulators (registers, live across the tile loop) ----
-  f32x16 gWh[2], gW2[LN > 0 ? LN : 1][2][2], gW1[2][2];
+  f32x16 gWh[1][2], gW2[LN > 0 ? LN : 1][2][2], gW1[2][2];
   // raw products: gW*[f][k] = sum_s dz[f][s] * xhat_in[k][s] (LayerNorm affine of the input NOT applied), gB = sum_s dz.
   // The epilogue turns them into weight, LayerNorm-affine and feature-norm gradients.
   float gBh = 0.f;
@@ -726,7 +768,7 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gWh[i][r] = 0.f;
+    for (int r = 0; r < 16; ++r) gWh[0][i][r] = 0.f;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -809,8 +851,8 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
         const int s = 2 * ss + half;
         const float av = (l31 < A) ? tZ[s * TP + l31] : 0.f;
         bsum += av;
-        gWh[0] = mfma(av, tLast[l31 * TP + s], gWh[0]);
-        gWh[1] = mfma(av, tLast[(32 + l31) * TP + s], gWh[1]);
+        gWh[0][0] = mfma(av, tLast[l31 * TP + s], gWh[0][0]);
+        gWh[0][1] = mfma(av, tLast[(32 + l31) * TP + s], gWh[0][1]);
       }
       gBh += xhalf_sum(bsum);
     }
@@ -926,7 +968,6 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
       STAMP(10);
     }
   }
-  STAMP(11);    // (loop exit)
 
   // ---- loss statistics of this workgroup ----
   if (HEAD == 1 || HEAD == 2) {
@@ -936,6 +977,27 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
       for (int k = 0; k < 4; ++k) p.partials[(size_t)blockIdx.x * 4 + k] = lacc[k];
     }
   }
+
+  // ---- raw products -> gradient partials (per wave, registers; see raw_to_grad) ----
+  const bool fnorm = p.desc.use_feature_norm != 0;
+  float vLnW[LN + 1], vLnB[LN + 1], vFnW = 0.f, vFnB = 0.f;      // lane = k
+  {
+    float *scr = lds + m.scratch + wave * HID;
+#pragma unroll
+    for (int j = 0; j <= LN; ++j) { vLnW[j] = 0.f; vLnB[j] = 0.f; }
+    if (HEAD != 3) {
+      raw_to_grad<1>(gWh, (lane < TS && l31 < A) ? gBh : 0.f, scr, lds + m.wh, HP, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN),
+                     HID, true, lane, l31, half, vLnW[LN], vLnB[LN]);
+    } else {
+      vLnW[LN] = gLnW; vLnB[LN] = gLnB;
+    }
+#pragma unroll
+    for (int l = LN - 1; l >= 0; --l)
+      raw_to_grad<2>(gW2[l], gB[l + 1], scr, lds + m.w2[l], WP, lds + ln_w_of<LN>(m, l), lds + ln_b_of<LN>(m, l), HID, true, lane, l31,
+                     half, vLnW[l], vLnB[l]);
+    if (!XWIDE && fnorm) raw_to_grad<2>(gW1, gB[0], scr, lds + m.w1, WP, lds + m.fn_w, lds + m.fn_b, D, wide, lane, l31, half, vFnW, vFnB);
+  }
+  STAMP(11);
 
   // ---- reduce the waves' accumulators through LDS (two regions, waves pair up) and write the slab ----
   __syncthreads();
@@ -973,19 +1035,25 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { const int a = ROWMAP(r, half); old[r] = (!first && a < A) ? red[o.wh + a * HID + 32 * tj + l31] : 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { const int a = ROWMAP(r, half); if (a < A) red[o.wh + a * HID + 32 * tj + l31] = old[r] + gWh[tj][r]; }
+        for (int r = 0; r < 16; ++r) { const int a = ROWMAP(r, half); if (a < A) red[o.wh + a * HID + 32 * tj + l31] = old[r] + gWh[0][tj][r]; }
       }
       {
-        constexpr int NVAL = LN + 4;
+        constexpr int NVAL = 3 * (LN + 1) + 3;
         float vals[NVAL]; int idx[NVAL]; bool ok[NVAL];
         int n = 0;
         vals[n] = gB[0]; idx[n] = o.b1 + lane; ok[n++] = true;
+        vals[n] = vLnW[0]; idx[n] = o.ln1_w + lane; ok[n++] = true;
+        vals[n] = vLnB[0]; idx[n] = o.ln1_b + lane; ok[n++] = true;
 #pragma unroll
-        for (int l = 0; l < LN; ++l) { vals[n] = gB[l + 1]; idx[n] = o.b2[l] + lane; ok[n++] = true; }
+        for (int l = 0; l < LN; ++l) {
+          vals[n] = gB[l + 1]; idx[n] = o.b2[l] + lane; ok[n++] = true;
+          vals[n] = vLnW[l + 1]; idx[n] = o.ln2_w[l] + lane; ok[n++] = true;
+          vals[n] = vLnB[l + 1]; idx[n] = o.ln2_b[l] + lane; ok[n++] = true;
+        }
         vals[n] = gBh; idx[n] = (HEAD != 3) ? o.bh + l31 : 0; ok[n++] = (HEAD != 3 && half == 0 && l31 < A);
-        const int lw = (LN == 0) ? o.ln1_w : o.ln2_w[LN > 0 ? LN - 1 : 0], lb = (LN == 0) ? o.ln1_b : o.ln2_b[LN > 0 ? LN - 1 : 0];
-        vals[n] = gLnW; idx[n] = lw + lane; ok[n++] = (HEAD == 3);
-        vals[n] = gLnB; idx[n] = lb + lane; ok[n++] = (HEAD == 3);
+        const bool fn = !XWIDE && fnorm && lane < D;
+        vals[n] = vFnW; idx[n] = o.fn_w + lane; ok[n++] = fn;
+        vals[n] = vFnB; idx[n] = o.fn_b + lane; ok[n++] = fn;
         float old[NVAL];
 #pragma unroll
         for (int i = 0; i < NVAL; ++i) old[i] = (!first && ok[i]) ? red[idx[i]] : 0.f;
@@ -996,81 +1064,12 @@ __global__ __launch_bounds__(256, 1) void mlp_update_kernel(UpdArgs p) {
     __syncthreads();
   }
   STAMP(12);    // block reduction through LDS
-
-  // ---- epilogue: raw products -> gradients, written straight to this workgroup's slab -------------------------------
-  // With h_in = xhat_in*gamma + beta feeding  z = W h_in + b,  G[f][k] = sum_s dz[f][s] xhat_in[k][s],  db[f] = sum_s dz[f][s]:
-  //   dW[f][k] = gamma[k] G[f][k] + beta[k] db[f]      d gamma[k] = sum_f W[f][k] G[f][k]      d beta[k] = sum_f W[f][k] db[f]
-  // (all linear in G and db, so they commute with the cross-workgroup slab sum that follows).
-  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;     // absolute flat offsets below
-  auto R = [&](int e) -> float { return n_reg > 1 ? red0[e] + red0[P + e] : red0[e]; };
-  const int tid = threadIdx.x, kk = tid & 63, f0 = tid >> 6, fstep = blockDim.x >> 6;
-  const bool fnorm = p.desc.use_feature_norm != 0;
-  // weight matrices (thread = column k, rows strided)
-  if (!XWIDE && kk < D) {
-    const float g = fnorm ? lds[m.fn_w + kk] : 1.f, bt = fnorm ? lds[m.fn_b + kk] : 0.f;
-    for (int f = f0; f < HID; f += fstep) slab[o.w1 + f * D + kk] = g * R(o.w1 + f * D + kk) + bt * R(o.b1 + f);
-  }
-#pragma unroll
-  for (int l = 0; l < LN; ++l) {
-    const float g = lds[ln_w_of<LN>(m, l) + kk], bt = lds[ln_b_of<LN>(m, l) + kk];
-    for (int f = f0; f < HID; f += fstep) slab[o.w2[l] + f * HID + kk] = g * R(o.w2[l] + f * HID + kk) + bt * R(o.b2[l] + f);
-  }
-  if (HEAD != 3) {
-    const float g = lds[ln_w_of<LN>(m, LN) + kk], bt = lds[ln_b_of<LN>(m, LN) + kk];
-    for (int a = f0; a < A; a += fstep) slab[o.wh + a * HID + kk] = g * R(o.wh + a * HID + kk) + bt * R(o.bh + a);
-  }
-  // vectors, one 64-wide group per wave at a time (wave-uniform branches, compile-time offsets; lane = k):
-  // biases as accumulated; LayerNorm / feature-norm affine from the consumer's weights and raw products
-  {
-    int g = 0;                                            // running group index (compile-time after unrolling)
-    auto mine = [&](int gi) { return (gi % n_waves) == wave; };
-    if (mine(g)) slab[o.b1 + lane] = R(o.b1 + lane);
-    ++g;
-#pragma unroll
-    for (int l = 0; l < LN; ++l) {
-      if (mine(g)) slab[o.b2[l] + lane] = R(o.b2[l] + lane);
-      ++g;
-    }
-#pragma unroll
-    for (int j = 0; j <= LN; ++j) {                       // LayerNorm j (tile tH[j]) feeds hidden layer j, or the head
-      const int ow = (j == 0) ? o.ln1_w : o.ln2_w[j > 0 ? j - 1 : 0], ob = (j == 0) ? o.ln1_b : o.ln2_b[j > 0 ? j - 1 : 0];
-      if (j < LN) {
-        if (mine(g)) {
-          const float *sW = lds + m.w2[j < LN ? j : 0];
-          const int gw = o.w2[j < LN ? j : 0], gb = o.b2[j < LN ? j : 0];
-          float dg = 0.f, db = 0.f;
-#pragma unroll 4
-          for (int f = 0; f < HID; ++f) { const float w = sW[lane * WP + f]; dg += w * R(gw + f * HID + lane); db += w * R(gb + f); }
-          slab[ow + lane] = dg;
-          slab[ob + lane] = db;
-        }
-      } else if (HEAD != 3) {
-        if (mine(g)) {
-          const float *sW = lds + m.wh;
-          float dg = 0.f, db = 0.f;
-          for (int a = 0; a < A; ++a) { const float w = sW[lane * HP + a]; dg += w * R(o.wh + a * HID + lane); db += w * R(o.bh + a); }
-          slab[ow + lane] = dg;
-          slab[ob + lane] = db;
-        }
-      } else {                                            // HEAD 3: accumulated directly by ln_act_backward<.., true>
-        if (mine(g)) { slab[ow + lane] = R(ow + lane); slab[ob + lane] = R(ob + lane); }
-      }
-      ++g;
-    }
-    if (fnorm && !XWIDE) {                                // feature norm feeds layer 1
-      if (mine(g) && lane < D) {
-        const float *sW = lds + m.w1;
-        float dg = 0.f, db = 0.f;
-#pragma unroll 4
-        for (int f = 0; f < HID; ++f) { const float w = sW[lane * WP + f]; dg += w * R(o.w1 + f * D + lane); db += w * R(o.b1 + f); }
-        slab[o.fn_w + lane] = dg;
-        slab[o.fn_b + lane] = db;
-      }
-      ++g;
-    }
-    if (HEAD != 3) {
-      if (mine(g) && lane < A) slab[o.bh + lane] = R(o.bh + lane);
-    }
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0 + rb;
+  const float *redv = red0 + rb;
+  if (n_reg > 1) {
+    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = redv[e] + redv[P + e];
+  } else {
+    for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = redv[e];
   }
   STAMP(13);    // slab write
   STAMP_FLUSH();
