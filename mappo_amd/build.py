@@ -22,17 +22,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, extra_flags=(), lib=None, objdir=None):
+    """Compile every csrc/*.hip (in parallel) and link `lib` (default: the in-tree product library).  `extra_flags`,
+    `lib`, `objdir` serve diagnostic builds (scripts/stamps.py) that must not touch the product library."""
+    lib = lib or LIB
     srcs = sources()
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(os.path.dirname(HERE), "include", "mappo_hip.h"))
     objs = []
     procs = []
     for s in srcs:
-        o = s[:-4] + ".o"
+        o = s[:-4] + ".o" if objdir is None else os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -46,12 +49,12 @@ def build(force=False, verbose=True):
             print(f"FAILED: {s}\n{out}", file=sys.stderr)
     if failed:
         raise RuntimeError("hipcc failed")
-    if force or procs or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if force or procs or _stale(lib, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

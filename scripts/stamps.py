@@ -5,8 +5,9 @@ import torch
 sys.path.insert(0, '.')
 ROOT = os.getcwd()
 out = os.path.join(ROOT, 'gpurun_out', 'libmappo_hip_stamps.so')
-srcs = [os.path.join(ROOT, 'mappo_amd', 'csrc', f) for f in sorted(os.listdir(os.path.join(ROOT, 'mappo_amd', 'csrc'))) if f.endswith('.hip')]
-subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-DMLP_STAMPS', '-w'] + os.environ.get('STAMP_FLAGS', '').split() + [ '-o', out] + srcs)
+from mappo_amd import build as _build
+objdir = os.path.join(ROOT, 'gpurun_out', 'stamps_obj'); os.makedirs(objdir, exist_ok=True)
+_build.build(force=True, verbose=False, extra_flags=['-DMLP_STAMPS', '-w'] + os.environ.get('STAMP_FLAGS', '').split(), lib=out, objdir=objdir)
 from mappo_amd import _lib
 _lib.LIB_PATH = out
 _lib.SIGNATURES['mappo_debug_set_stamps'] = (ctypes.c_int, [ctypes.c_void_p])
