@@ -50,7 +50,7 @@ extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
 struct LdsMap {
   int w1, w2[MAPPO_MAX_LAYER_N], wh;
   int fn_w, fn_b, b1, ln1_w, ln1_b, b2[MAPPO_MAX_LAYER_N], ln2_w[MAPPO_MAX_LAYER_N], ln2_b[MAPPO_MAX_LAYER_N], bh;
-  int scratch;       // n_waves x 64 floats: per-wave vector scratch of the update kernel's epilogue
+  int scratch;       // n_waves x 192 floats: exchange buffers / epilogue scratch of the update kernels
   int tiles, x_rows, wave_stride, total;
   int fn_size;       // floats reserved per feature-norm vector (64, or in_dim rounded up to 64 for wide inputs)
 };
@@ -72,7 +72,7 @@ __host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves) 
     if (l < d.layer_N) { m.b2[l] = p; p += HID; m.ln2_w[l] = p; p += HID; m.ln2_b[l] = p; p += HID; }
   }
   m.bh = p; p += 32;
-  m.scratch = p; p += n_waves * HID;
+  m.scratch = p; p += n_waves * 192;           // update kernels: exchange buffers + epilogue scratch
   m.tiles = p;
   m.x_rows = Dp;
   m.wave_stride = al4((Dp + (d.layer_N + 1) * HID + TS) * TP);
@@ -1141,6 +1141,8 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
   STAMP_FLUSH();
 }
 
+#include "mlp_upd2.h"
+
 #define LDS_LIMIT (160 * 1024)
 #define LDS_STATIC 1024                      // static __shared__ of the kernels (reduction scratch), rounded up
 #define LDS_DYN_MAX (LDS_LIMIT - LDS_STATIC) // what hipFuncAttributeMaxDynamicSharedMemorySize may be raised to
@@ -1151,6 +1153,9 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
 // host entry points and every other kernel.
 template <bool R, int L, int HEAD>
 int upd_inst(int xw, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who);
+// pair kernel (mlp_upd2.h), in_dim <= 64: translation units mlp_upd2_r{0,1}_l{0,1,2}.hip
+template <bool R, int L, int HEAD>
+int upd2_inst(bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who);
 
 #ifdef MLP_TU_UPD
 template <bool R, int L, int HEAD, int W>
@@ -1167,14 +1172,36 @@ static int upd_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, c
 }
 template <bool R, int L, int HEAD>
 int upd_inst(int xw, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who) {
-  if (xw == 2) return upd_launch<R, L, HEAD, 2>(grid, block, lds_bytes, st, a, who);
-  if (xw == 1) return upd_launch<R, L, HEAD, 1>(grid, block, lds_bytes, st, a, who);
-  return upd_launch<R, L, HEAD, 0>(grid, block, lds_bytes, st, a, who);
+  if (xw != 2) { mappo_set_error("%s: in_dim <= 64 is served by the pair kernel", who); return MAPPO_EINVAL; }
+  return upd_launch<R, L, HEAD, 2>(grid, block, lds_bytes, st, a, who);
 }
 template int upd_inst<MLP_UPD_RELU, MLP_UPD_LN, 0>(int, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
 template int upd_inst<MLP_UPD_RELU, MLP_UPD_LN, 1>(int, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
 template int upd_inst<MLP_UPD_RELU, MLP_UPD_LN, 2>(int, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
 template int upd_inst<MLP_UPD_RELU, MLP_UPD_LN, 3>(int, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
+#endif
+
+#ifdef MLP_TU_UPD2
+template <bool R, int L, int HEAD, bool W>
+static int upd2_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update2_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_DYN_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update2_kernel<R, L, HEAD, W>), grid, block, lds_bytes, st, a);
+  return MAPPO_OK;
+}
+template <bool R, int L, int HEAD>
+int upd2_inst(bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who) {
+  return wide ? upd2_launch<R, L, HEAD, true>(grid, block, lds_bytes, st, a, who) : upd2_launch<R, L, HEAD, false>(grid, block, lds_bytes, st, a, who);
+}
+template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 0>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
+template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 1>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
+template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 2>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
+template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 3>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
 #endif
 
 #ifdef MLP_TU_MAIN
@@ -1288,31 +1315,48 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
   a.off = net_offsets(d);
   MAPPO_REQUIRE(a.slab_col0 >= 0 && a.slab_col0 + a.off.total <= a.slab_stride, "%s: slab column range", who);
   const int LN = d.layer_N;
-  const int nw = fit_waves(d, UPD_THREADS / WAVE);
-  a.map = lds_map(d, nw);
-  const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
-  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
+  const bool relu = d.use_relu != 0;
   a.p_red = (HEAD == 3 && d.recurrent) ? a.off.gru_wih : a.off.total;
-  a.red_base = d.in_dim > MAXD ? a.off.b1 : 0;
-  MAPPO_REQUIRE(d.in_dim <= MAXD || a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
-  const int p_span = a.p_red - a.red_base;
-  a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * p_span) ? 2 : 1;
-  MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * p_span, "%s: reduction buffer too small", who);
   int nb = mappo_mlp_backward_slabs(a.B);          // every slab the caller sized for is written: grid == that count
   if (a.n_blocks > 0) {                            // caller-chosen grid (actor and critic side by side on disjoint CUs)
     MAPPO_REQUIRE(a.n_blocks <= NUM_CU, "%s: n_blocks %d > %d", who, a.n_blocks, NUM_CU);
     nb = a.n_blocks < nb ? a.n_blocks : nb;
   }
-  dim3 grid((unsigned)nb), block(WAVE * nw);
-  const bool relu = d.use_relu != 0;
-  const int xw = d.in_dim > MAXD ? 2 : (d.in_dim > 32 ? 1 : 0);
 #ifdef MLP_STAMPS
   a.stamps = g_stamp_host;
 #endif
   int rc;
-  if (LN == 0) rc = relu ? upd_inst<true, 0, HEAD>(xw, grid, block, lds_bytes, st, a, who) : upd_inst<false, 0, HEAD>(xw, grid, block, lds_bytes, st, a, who);
-  else if (LN == 1) rc = relu ? upd_inst<true, 1, HEAD>(xw, grid, block, lds_bytes, st, a, who) : upd_inst<false, 1, HEAD>(xw, grid, block, lds_bytes, st, a, who);
-  else rc = relu ? upd_inst<true, 2, HEAD>(xw, grid, block, lds_bytes, st, a, who) : upd_inst<false, 2, HEAD>(xw, grid, block, lds_bytes, st, a, who);
+  if (d.in_dim <= MAXD) {
+    // pair kernel (mlp_upd2.h): n_pairs tiles in flight per workgroup, two waves each
+    const int np = fit_waves(d, 4);
+    a.map = lds_map(d, np);
+    const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
+    MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
+    a.red_base = 0;
+    const int tile_area = np * a.map.wave_stride, vec_floats = 2 * np * (3 * (LN + 1) + 3) * 64;
+    a.n_regions = (np > 1 && 2 * a.p_red + vec_floats <= tile_area) ? 2 : 1;
+    MAPPO_REQUIRE(a.n_regions * a.p_red + vec_floats <= tile_area, "%s: reduction buffer too small", who);
+    dim3 grid((unsigned)nb), block(2 * WAVE * np);
+    const bool wide = d.in_dim > 32;
+    if (LN == 0) rc = relu ? upd2_inst<true, 0, HEAD>(wide, grid, block, lds_bytes, st, a, who) : upd2_inst<false, 0, HEAD>(wide, grid, block, lds_bytes, st, a, who);
+    else if (LN == 1) rc = relu ? upd2_inst<true, 1, HEAD>(wide, grid, block, lds_bytes, st, a, who) : upd2_inst<false, 1, HEAD>(wide, grid, block, lds_bytes, st, a, who);
+    else rc = relu ? upd2_inst<true, 2, HEAD>(wide, grid, block, lds_bytes, st, a, who) : upd2_inst<false, 2, HEAD>(wide, grid, block, lds_bytes, st, a, who);
+  } else {
+    // wide inputs: one wave per tile, layer 1 K-chunked; W1 / feature-norm gradients come from wide_l1_bwd_kernel
+    const int nw = fit_waves(d, UPD_THREADS / WAVE);
+    a.map = lds_map(d, nw);
+    const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
+    MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
+    a.red_base = a.off.b1;
+    MAPPO_REQUIRE(a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
+    const int p_span = a.p_red - a.red_base;
+    a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * p_span) ? 2 : 1;
+    MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * p_span, "%s: reduction buffer too small", who);
+    dim3 grid((unsigned)nb), block(WAVE * nw);
+    if (LN == 0) rc = relu ? upd_inst<true, 0, HEAD>(2, grid, block, lds_bytes, st, a, who) : upd_inst<false, 0, HEAD>(2, grid, block, lds_bytes, st, a, who);
+    else if (LN == 1) rc = relu ? upd_inst<true, 1, HEAD>(2, grid, block, lds_bytes, st, a, who) : upd_inst<false, 1, HEAD>(2, grid, block, lds_bytes, st, a, who);
+    else rc = relu ? upd_inst<true, 2, HEAD>(2, grid, block, lds_bytes, st, a, who) : upd_inst<false, 2, HEAD>(2, grid, block, lds_bytes, st, a, who);
+  }
   if (rc) return rc;
   MAPPO_CHECK_LAUNCH(who);
   return MAPPO_OK;

@@ -1,0 +1,5 @@
+// mlp_update2_kernel<RELU=false, LN=1, HEAD 0..3, WIDE 0..1> — the pair update kernel (see mlp_upd2.h)
+#define MLP_TU_UPD2
+#define MLP_UPD_RELU false
+#define MLP_UPD_LN 1
+#include "mlp_impl.h"
