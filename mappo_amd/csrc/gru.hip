@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
   extern __shared__ __align__(16) float lds[];
   const GruLds &m = p.map;
   const int n_waves = blockDim.x / WAVE;
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   stage_gru_all(lds, m, p.params, p.off, p.A, true, p.head_mode != 0);
   __syncthreads();
   float *tHm = lds + m.tiles + wave * m.wave_stride;     // [64][TP] masked previous state (B operand)
@@ -572,7 +572,7 @@ struct GruWgArgs {
 
 __global__ __launch_bounds__(256, 1) void gru_wgrad_kernel(GruWgArgs p) {
   extern __shared__ __align__(16) float lds[];
-  const int lane = threadIdx.x & (WAVE - 1), role = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & (WAVE - 1), role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   const int mat = role >> 1, ghalf = role & 1;              // mat 0: W_ih (x), 1: W_hh (hm)
   float *tA = lds + role * ((96 + HID) * TP);                // [96][TP] dG rows of this role
   float *tB = tA + 96 * TP;                                  // [64][TP] input tile

@@ -56,7 +56,19 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, WAVE); }
+// v(lane) + v(lane ^ 32): one v_permlane32_swap (gfx950) instead of a ds_bpermute round trip through the LDS crossbar.
+// With vdst = src = v the swap leaves {lo, lo} in one result and {hi, hi} in the other, so their sum is lo + hi in every lane.
+__device__ __forceinline__ float xhalf_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// v(lane) + v(lane ^ 16)
+__device__ __forceinline__ float xrow_sum(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 // fire-and-forget LDS float add (ds_add_f32): used where exactly one wave adds into a location per phase, so the
 // result does not depend on arrival order

@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
   const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)D) + 1u;
   const int64_t n_tiles = (p.B + TS - 1) / TS;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
 // In the product build STAMP() expands to nothing and no stamp executes.
 // ------------------------------------------------------------------------------------------------
 #ifdef MLP_STAMPS
-#define N_STAMPS 16
+#define N_STAMPS 24
 static unsigned long long *g_stamp_host = nullptr;          // [gridDim.x][N_STAMPS], set by mappo_debug_set_stamps (main TU)
 #define STAMP_DECL unsigned long long st_acc_[N_STAMPS] = {}; unsigned long long st_prev_ = __builtin_readcyclecounter();
 #define STAMP(i)                                                          \
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
   const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)D) + 1u;
   constexpr bool wide = WIDE;        // second 32-wide tile over the input features in use
@@ -1439,7 +1439,7 @@ struct WideArgs {
 
 __global__ __launch_bounds__(256, 1) void wide_l1_bwd_kernel(WideArgs p) {
   extern __shared__ __align__(16) float lds[];
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   const int D = p.D, c0 = blockIdx.y * MAXD, kc = min(MAXD, D - c0);
   float *sW = lds;                                   // [64 kk][WP]  W1 chunk, k-major
   float *sG = sW + MAXD * WP, *sBt = sG + MAXD;      // gamma0 / beta0 of the chunk

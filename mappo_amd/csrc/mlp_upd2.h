@@ -10,13 +10,41 @@
 // LDS footprint per tile is unchanged (the pair shares the tile's xhat / dz tiles).  What the split costs:
 //   * LayerNorm statistics span both halves: each wave reduces its 32 features (mean, M2), the halves meet through a
 //     64-float exchange buffer and combine with Chan's formula (forward), resp. add their partial sums (backward);
-//   * a workgroup barrier wherever one wave consumes rows its partner produced (11 per tile for layer_N = 1).  All
-//     waves run the same uniform tile loop, so every barrier is reached by every wave.
+//   * a PAIR barrier (pair_sync: an LDS counter, not s_barrier) wherever one wave consumes rows its partner produced
+//     (11 per tile for layer_N = 1).  Pairs are not synchronised with each other inside the tile loop, so the two
+//     tiles that share a SIMD drift apart and fill each other's MFMA / VALU / LDS latencies.
 //   * the head forward + per-sample loss (32 lanes of work) is done by wave 0 of the pair while wave 1 waits.
 // Accumulated quantities are the RAW products (see raw_to_grad in mlp_impl.h); the epilogue is per wave.
 #pragma once
 
 #define XS 65            // row stride (floats) of the flat-commit staging area: lanes (s16, q) hit 64 distinct banks
+
+// Barrier between the TWO waves of a pair (gfx950 has only the workgroup-wide s_barrier, and that would keep all 8
+// waves of the workgroup in the same phase — the co-resident waves of a SIMD then want the MFMA pipe, or the VALU, at
+// the same time).  Arrive = one LDS atomic increment, wait = poll until both arrivals of this epoch are in.  Both waves
+// are resident for the life of the workgroup, so the wait cannot deadlock; a wave's LDS operations execute in issue
+// order, so everything it wrote before arriving is visible to the partner once the partner sees the count.
+struct PairSync {
+  unsigned *cnt; unsigned epoch;
+#ifdef MLP_STAMPS
+  unsigned long long cyc;     // diagnostic build: cycles spent inside pair_sync
+#endif
+};
+__device__ __forceinline__ void pair_sync(PairSync &ps, int lane) {
+  // No fence: a workgroup-scope release would also wait for the global prefetch loads in flight (vmcnt), which is
+  // exactly what must stay asynchronous.  Only the compiler has to keep the LDS accesses on their side of the barrier.
+  asm volatile("" ::: "memory");
+#ifdef MLP_STAMPS
+  const unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
+  ps.epoch += 2u;
+  if (lane == 0) (void)__hip_atomic_fetch_add(ps.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  while (__hip_atomic_load(ps.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ps.epoch) { }
+#ifdef MLP_STAMPS
+  ps.cyc += __builtin_readcyclecounter() - t0_;
+#endif
+  asm volatile("" ::: "memory");
+}
 
 template <bool WIDE>
 struct HalfPrefetch {
@@ -54,38 +82,37 @@ __device__ __forceinline__ void prefetch_half(HalfPrefetch<WIDE> &pf, const floa
   }
 }
 
-__device__ __forceinline__ float quad_sum(float v) {       // over the 4 lanes (q = 0..3) that share a sample
-  v += __shfl_xor(v, 16, WAVE);
-  return v + __shfl_xor(v, 32, WAVE);
-}
+__device__ __forceinline__ float quad_sum(float v) { return xhalf_sum(xrow_sum(v)); }   // over the 4 lanes (q) of a sample
 
-// tX[k][16 fh + s16] <- xhat0 (or the raw input); tF: 16*XS floats of dead wave-private staging (flat mode)
+// tX[k][16 fh + s16] <- xhat0 (or the raw input).  tF: this wave's 16*XS floats of dead staging (flat mode); `dummy`: a
+// dead LDS word that absorbs the stores of lanes with nothing to write (address select instead of a branch per
+// element: hipcc otherwise wraps every store in its own exec-mask region and waits for every load on its own).
 template <bool WIDE>
-__device__ __forceinline__ void commit_half(float *tX, float *tF, const HalfPrefetch<WIDE> &pf, int D, int Dp, uint32_t magic, int lane,
-                                            int fh, bool feature_norm) {
+__device__ __forceinline__ void commit_half(float *tX, float *tF, float *dummy, const HalfPrefetch<WIDE> &pf, int D, int Dp, float inv_D,
+                                            uint32_t magic, int lane, int fh, bool feature_norm) {
   constexpr int NV = WIDE ? 16 : 8;
   int ln = lane;
-  asm volatile("" : "+v"(ln));        // opaque per tile: keeps hipcc from hoisting 16+ lane predicates into SGPR pairs
+  asm volatile("" : "+v"(ln));        // opaque per tile: keeps hipcc from hoisting the lane predicates into SGPR pairs
   const int s16 = ln & 15, q = ln >> 4, s = 16 * fh + s16;
   float v[NV];
   if (pf.flat) {
 #pragma unroll
-    for (int j = 0; j < NV / 4; ++j)
+    for (int j = 0; j < NV / 4; ++j) {
+      const bool in = (ln + 64 * j) < 4 * D;                 // whole float4 chunks: 16*D is a multiple of 4
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int e = 4 * (ln + 64 * j) + c;
-        if (e < 16 * D) {
-          const int r = (int)__umulhi((uint32_t)e, magic);
-          tF[r * XS + (e - r * D)] = pf.v[4 * j + c];
-        }
+        const int r = (int)__umulhi((uint32_t)e, magic);
+        float *dst = in ? tF + r * XS + (e - r * D) : dummy;
+        *dst = pf.v[4 * j + c];
       }
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      const int k = NV * q + j;
-      const float t = tF[s16 * XS + min(k, D - 1)];
-      v[j] = (k < D) ? t : 0.f;
     }
+    wave_lds_sync();
+    float t[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) t[j] = tF[s16 * XS + min(NV * q + j, D - 1)];      // all loads first, selected below
+#pragma unroll
+    for (int j = 0; j < NV; ++j) v[j] = (NV * q + j < D) ? t[j] : 0.f;
   } else {
 #pragma unroll
     for (int j = 0; j < NV; ++j) v[j] = pf.v[j];             // slots beyond D hold 0
@@ -95,16 +122,17 @@ __device__ __forceinline__ void commit_half(float *tX, float *tF, const HalfPref
     float sum = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) sum += v[j];
-    mean = quad_sum(sum) / (float)D;
+    mean = quad_sum(sum) * inv_D;
     float qq = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; ++j) { const float c = (NV * q + j < D) ? v[j] - mean : 0.f; qq += c * c; }
-    rstd = 1.0f / sqrtf(quad_sum(qq) / (float)D + LN_EPS);
+    rstd = 1.0f / sqrtf(quad_sum(qq) * inv_D + LN_EPS);
   }
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     const int k = NV * q + j;
-    if (k < Dp) tX[k * TP + s] = (k < D) ? (v[j] - mean) * rstd : 0.f;
+    float *dst = (k < Dp) ? tX + k * TP + s : dummy;
+    *dst = (k < D) ? (v[j] - mean) * rstd : 0.f;
   }
 }
 
@@ -134,10 +162,10 @@ struct TileStats1 {
 };
 
 // act + LayerNorm over 64 features of which this wave holds 32: local (mean, M2), exchange, Chan combine; xhat -> tile.
-// Contains one workgroup barrier (exchange); the caller places the barrier that publishes the tile.
+// Contains one pair barrier (exchange); the caller places the barrier that publishes the tile.
 template <bool RELU>
-__device__ __forceinline__ void act_ln_to_tile1(f32x16 &acc, float *tile, float *xch, int fh, int l31, int half, float &mean,
-                                                float &rstd, uint32_t &pos) {
+__device__ __forceinline__ void act_ln_to_tile1(f32x16 &acc, float *tile, float *xch, PairSync &ps, int fh, int lane, int l31, int half,
+                                                float &mean, float &rstd, uint32_t &pos) {
   float s = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc[r] = act_fwd<RELU>(acc[r]); s += acc[r]; }
@@ -149,7 +177,7 @@ __device__ __forceinline__ void act_ln_to_tile1(f32x16 &acc, float *tile, float 
   const float M2_loc = xhalf_sum(q);
   pos = mk;
   if (half == 0) { xch[fh * 64 + l31] = m_loc; xch[fh * 64 + 32 + l31] = M2_loc; }
-  __syncthreads();
+  pair_sync(ps, lane);
   const float m_o = xch[(1 - fh) * 64 + l31], M2_o = xch[(1 - fh) * 64 + 32 + l31];
   const float d = m_loc - m_o;
   mean = 0.5f * (m_loc + m_o);
@@ -167,11 +195,11 @@ __device__ __forceinline__ float half_row_sum(const float *tile, int row0, int l
   return xhalf_sum(s0 + s1);
 }
 
-// LayerNorm + activation backward for the 32 features of this wave (see ln_act_backward).  One workgroup barrier
+// LayerNorm + activation backward for the 32 features of this wave (see ln_act_backward).  One pair barrier
 // (exchange of the partial sums); the caller places the barrier that publishes dz.
 template <bool RELU, bool AFFINE>
-__device__ __forceinline__ void ln_act_backward1(f32x16 &dH, float *tile, float *xch, int fh, float mean, float rstd, uint32_t pos,
-                                                 const float *sG, float &gG, float &gB, int l31, int half) {
+__device__ __forceinline__ void ln_act_backward1(f32x16 &dH, float *tile, float *xch, PairSync &ps, int fh, float mean, float rstd,
+                                                 uint32_t pos, const float *sG, float &gG, float &gB, int lane, int l31, int half) {
   const int row0 = 32 * fh;
   float xh[16];
 #pragma unroll
@@ -206,7 +234,7 @@ __device__ __forceinline__ void ln_act_backward1(f32x16 &dH, float *tile, float 
   m1 = xhalf_sum(m1);
   m2 = xhalf_sum(m2);
   if (half == 0) { xch[fh * 64 + l31] = m1; xch[fh * 64 + 32 + l31] = m2; }
-  __syncthreads();
+  pair_sync(ps, lane);
   m1 = (m1 + xch[(1 - fh) * 64 + l31]) * (1.f / HID);
   m2 = (m2 + xch[(1 - fh) * 64 + 32 + l31]) * (1.f / HID);
   const float inv_rstd = 1.0f / rstd;
@@ -267,19 +295,28 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
   const int n_pairs = blockDim.x / (2 * WAVE);
-  const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE, l31 = lane & 31, half = lane >> 5;
-  const int pair = wave % n_pairs, fh = wave / n_pairs, row0 = 32 * fh;
+  const int lane = threadIdx.x & (WAVE - 1), l31 = lane & 31, half = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // wave-uniform: tile indices and bases stay scalar
+  const int pair = wave >> 1, fh = wave & 1, row0 = 32 * fh;     // partners sit on different SIMDs; a SIMD hosts two TILES
+  __shared__ unsigned pair_cnt[4];
+  if (threadIdx.x < 4) pair_cnt[threadIdx.x] = 0u;              // published by the barrier after the weight staging
+  PairSync ps = {};
+  ps.cnt = pair_cnt + pair;
   const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
   const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)D) + 1u;
+  const float inv_D = 1.0f / (float)D;
   const bool fnorm = p.desc.use_feature_norm != 0;
+  // Pairs are independent workers (their barriers are pair-local): worker w = pair * gridDim + block takes tiles
+  // w, w + W, w + 2W, ...  A tile count that is not a multiple of W then leaves its remainder spread over ALL CUs
+  // (first the pairs 0, then the pairs 1, ...) instead of a few workgroups running one more full round.
   const int64_t n_tiles = (p.B + TS - 1) / TS;
   const int64_t tile_stride = (int64_t)gridDim.x * n_pairs;
-  const int64_t n_btiles = (n_tiles + n_pairs - 1) / n_pairs;       // uniform tile loop: every wave reaches every barrier
+  const int64_t tile0 = (int64_t)pair * gridDim.x + blockIdx.x;
   HalfPrefetch<WIDE> pf;
   LossPrefetch lp;
   STAMP_DECL
   {
-    const int64_t base0 = ((int64_t)blockIdx.x * n_pairs + pair) * TS;
+    const int64_t base0 = tile0 * TS;
     prefetch_half(pf, p.x, p.rows, base0, p.B, D, lane, fh);
     const int nv = pf.n_valid;
     const int64_t row = (lane < nv) ? (p.rows ? (int64_t)p.rows[base0 + lane] : base0 + lane) : 0;
@@ -310,13 +347,13 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
 #pragma unroll
   for (int l = 0; l <= LN; ++l) gB[l] = 0.f;
 
-  for (int64_t tb = blockIdx.x; tb < n_btiles; tb += gridDim.x) {
-    const int64_t tile = tb * n_pairs + pair;
+  for (int64_t tile = tile0; tile < n_tiles; tile += tile_stride) {
     const int64_t base = tile * TS;
     const int n_valid = pf.n_valid;
     const LossPrefetch cur = lp;
     TileStats1<LN> st;
-    commit_half(tX, tF, pf, D, Dp, magic, lane, fh, fnorm);
+    commit_half(tX, tF, tH + 2 * 16 * XS, pf, D, Dp, inv_D, magic, lane, fh, fnorm);
+    STAMP(16);  // commit
     {
       const int64_t nbase = (tile + tile_stride) * TS;
       prefetch_half(pf, p.x, p.rows, nbase, p.B, D, lane, fh);                   // next tile, hidden under the MFMAs below
@@ -324,21 +361,22 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
       const int64_t row = (lane < nv) ? (p.rows ? (int64_t)p.rows[nbase + lane] : nbase + lane) : 0;
       if (fh == 0) prefetch_loss<HEAD>(lp, p, row, nv, lane, A);
     }
-    __syncthreads();                                     // both halves of tX written
-    STAMP(1);   // commit (+ feature norm) + prefetch issue
+    STAMP(17);  // prefetch issue
+    pair_sync(ps, lane);                                     // both halves of tX written
+    STAMP(1);   // sync after commit
     // ---- trunk forward (this wave: features row0..row0+31 of every layer) ----
     {
       f32x16 acc;
       init_bias1(acc, lds + m.b1, fh, half);
       layer_mfma1(acc, lds + m.w1 + row0, tX, lds + m.fn_w, lds + m.fn_b, Dp / 2, l31, half);
-      act_ln_to_tile1<RELU>(acc, tH, xch, fh, l31, half, st.mean[0], st.rstd[0], st.pos[0]);
-      __syncthreads();
+      act_ln_to_tile1<RELU>(acc, tH, xch, ps, fh, lane, l31, half, st.mean[0], st.rstd[0], st.pos[0]);
+      pair_sync(ps, lane);
 #pragma unroll
       for (int l = 0; l < LN; ++l) {
         init_bias1(acc, lds + m.b2[l], fh, half);
         layer_mfma1(acc, lds + m.w2[l] + row0, tH + l * HID * TP, lds + ln_w_of<LN>(m, l), lds + ln_b_of<LN>(m, l), HID / 2, l31, half);
-        act_ln_to_tile1<RELU>(acc, tH + (l + 1) * HID * TP, xch, fh, l31, half, st.mean[l + 1], st.rstd[l + 1], st.pos[l + 1]);
-        __syncthreads();
+        act_ln_to_tile1<RELU>(acc, tH + (l + 1) * HID * TP, xch, ps, fh, lane, l31, half, st.mean[l + 1], st.rstd[l + 1], st.pos[l + 1]);
+        pair_sync(ps, lane);
       }
     }
     float *tLast = tH + LN * HID * TP;
@@ -374,7 +412,7 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
           }
         }
       }
-      __syncthreads();
+      pair_sync(ps, lane);
     }
     STAMP(3);   // head forward + loss
 
@@ -410,10 +448,10 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
       float *tCur = tH + l * HID * TP;          // xhat of this layer's LayerNorm -> dz
       float *tPrev = tH + (l - 1) * HID * TP;   // xhat of the layer's input
       if (HEAD == 3 && l == LN)
-        ln_act_backward1<RELU, true>(dH, tCur, xch, fh, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW, gLnB, l31, half);
+        ln_act_backward1<RELU, true>(dH, tCur, xch, ps, fh, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW, gLnB, lane, l31, half);
       else
-        ln_act_backward1<RELU, false>(dH, tCur, xch, fh, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW, gLnB, l31, half);
-      __syncthreads();                          // all 64 rows of dz published
+        ln_act_backward1<RELU, false>(dH, tCur, xch, ps, fh, st.mean[l], st.rstd[l], st.pos[l], lds + m.ln2_w[l - 1], gLnW, gLnB, lane, l31, half);
+      pair_sync(ps, lane);                          // all 64 rows of dz published
       gB[l] += half_row_sum(tCur, row0, l31, half);
       STAMP(5);   // LN + act backward (hidden)
 #pragma unroll 2
@@ -440,9 +478,9 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
     {
       float *tCur = tH;
       if (HEAD == 3 && LN == 0)
-        ln_act_backward1<RELU, true>(dH, tCur, xch, fh, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW, gLnB, l31, half);
+        ln_act_backward1<RELU, true>(dH, tCur, xch, ps, fh, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW, gLnB, lane, l31, half);
       else
-        ln_act_backward1<RELU, false>(dH, tCur, xch, fh, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW, gLnB, l31, half);
+        ln_act_backward1<RELU, false>(dH, tCur, xch, ps, fh, st.mean[0], st.rstd[0], st.pos[0], lds + m.ln1_w, gLnW, gLnB, lane, l31, half);
       wave_lds_sync();                          // gW1 / db read only this wave's own dz rows
       gB[0] += half_row_sum(tCur, row0, l31, half);
       STAMP(8);   // LN + act backward (layer 1)
@@ -456,7 +494,7 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
       }
       STAMP(9);   // dW1
     }
-    __syncthreads();                            // tiles free for the next commit
+    pair_sync(ps, lane);                            // tiles free for the next commit
     STAMP(10);
   }
 
@@ -597,5 +635,8 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
     for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red0[e];
   }
   STAMP(13);    // slab write
+#ifdef MLP_STAMPS
+  st_acc_[14] = ps.cyc;      // (informational: contained in the phases above)
+#endif
   STAMP_FLUSH();
 }

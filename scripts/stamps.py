@@ -13,8 +13,8 @@ _lib.LIB_PATH = out
 _lib.SIGNATURES['mappo_debug_set_stamps'] = (ctypes.c_int, [ctypes.c_void_p])
 from mappo_amd import ops
 lib = _lib.load()
-NAMES = ['staging', 'commit+prefetch+featnorm', 'trunk fwd', 'head fwd + loss', 'head grads A,B', 'LNbwd hidden', 'dW2', 'dH hidden',
-         'LNbwd L1', 'dW1', 'dX + fn grads', 'loop exit + raw->grad', 'block reduce (LDS)', 'slab write', '', '']
+NAMES = ['staging', 'sync after commit', 'trunk fwd', 'head fwd + loss', 'head grads A,B', 'LNbwd hidden', 'dW2', 'dH hidden',
+         'LNbwd L1', 'dW1', 'dX + fn grads', 'loop exit + raw->grad', 'block reduce (LDS)', 'slab write', '(of which: pair_sync)', '', 'commit_half', 'prefetch issue', '', '', '', '', '', '']
 class A_: pass
 a = A_(); a.clip_param=0.2; a.entropy_coef=0.01; a.value_loss_coef=1.0; a.huber_delta=10.0; a.use_huber_loss=True; a.use_clipped_value_loss=True; a.use_policy_active_masks=True; a.use_value_active_masks=True; a.use_valuenorm=True
 cfg = ops.ppo_cfg(a)
@@ -26,7 +26,7 @@ for name, D, A in (('actor', 18, 5), ('critic', 54, 1)):
     slabs = torch.zeros(ns, P, device='cuda'); part = ops.update_partials('cuda')
     ret = torch.randn(B, device='cuda'); active = torch.ones(B, device='cuda')
     mom = torch.zeros(4, dtype=torch.float64, device='cuda'); ops.minibatch_moments(ret, active, None, B, mom)
-    stamps = torch.zeros(ns * 16, dtype=torch.int64, device='cuda')
+    stamps = torch.zeros(ns * 24, dtype=torch.int64, device='cuda')
     assert lib.mappo_debug_set_stamps(ctypes.c_void_p(stamps.data_ptr())) == 0
     def run():
         if name == 'actor':
@@ -37,7 +37,7 @@ for name, D, A in (('actor', 18, 5), ('critic', 54, 1)):
                               mom, cfg, slabs, P, 0, part)
     for _ in range(3): run()
     torch.cuda.synchronize()
-    st = stamps.view(ns, 16).double().cpu()
+    st = stamps.view(ns, 24).double().cpu()
     mean = st.mean(0); tot = mean.sum()
     print(f"--- {name} D={D} A={A} B={B}: {ns} blocks, mean cycles per block (wave 0) = {tot:.0f}")
     for i, n in enumerate(NAMES):
