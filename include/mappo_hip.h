@@ -143,6 +143,19 @@ int mappo_actor_act(const float *params, const mappo_net_desc *desc /*host*/, co
                     const float *avail /*[B][A] or NULL*/, int64_t B, int32_t deterministic,
                     uint64_t seed, uint64_t counter, const uint64_t *counter_dev /*device word added to counter, or NULL*/,
                     float *actions /*[B] fp32 (buffer dtype)*/, float *logp /*[B]*/, mappo_stream_t stream);
+/* One launch per rollout step (mpe_runner.py:95-139): actor get_actions + critic get_values (+ optionally the insert
+ * of the env output the rows are read from).  Rows may be strided views of the env's output: with M > 0 sample i is
+ * (thread n, agent m) = (i / M, i % M) and starts at base[n*stride_n + m*stride_m]; M == 0: contiguous [B][in_dim].
+ * obs_dst != NULL additionally performs mappo_insert_mpe(obs, rewards, dones -> obs_dst, share_dst, rew_dst, mask_dst)
+ * (N = B / M threads) inside the same launch.  Networks with in_dim <= 64 that share layer_N and the activation. */
+int mappo_rollout_step(const float *actor_params, const mappo_net_desc *actor_desc /*host*/, const float *critic_params,
+                       const mappo_net_desc *critic_desc /*host*/, const float *obs, int64_t obs_stride_n,
+                       int64_t obs_stride_m, const float *share_obs, int64_t share_stride_n, int64_t share_stride_m,
+                       int32_t M, int64_t B, const float *avail /*[B][A] or NULL*/, int32_t deterministic, uint64_t seed,
+                       uint64_t counter, const uint64_t *counter_dev, float *actions /*[B]*/, float *logp /*[B]*/,
+                       float *values /*[B]*/, float *obs_dst /*or NULL: no insert*/, float *share_dst, const float *rewards,
+                       int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones, int64_t done_stride_n,
+                       int64_t done_stride_m, float *rew_dst, float *mask_dst, int32_t centralized, mappo_stream_t stream);
 int32_t mappo_mlp_backward_slabs(int64_t B); /* number of slabs the launch below will write */
 int mappo_mlp_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x,
                        const int32_t *rows, int64_t B, const float *dout /*[B][out_dim]*/,

@@ -45,6 +45,8 @@ SIGNATURES = {
     "mappo_ppo_loss_fwd_bwd": (C.c_int, [_P] * 16 + [C.POINTER(PpoCfg), _I64, _I32, _P]),
     "mappo_mlp_forward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P]),
     "mappo_actor_act": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _I32, _U64, _U64, _P, _P, _P, _P]),
+    "mappo_rollout_step": (C.c_int, [_P, C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _I64, _I64, _P, _I64, _I64, _I32, _I64, _P, _I32,
+                                     _U64, _U64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _I32, _P]),
     "mappo_mlp_backward_slabs": (_I32, [_I64]),
     "mappo_mlp_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _I64, _I64, _P, _P]),
     "mappo_wide_workspace_floats": (_I64, [_I64]),

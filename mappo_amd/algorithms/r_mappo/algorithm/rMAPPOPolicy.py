@@ -129,6 +129,54 @@ class R_MAPPOPolicy:
         actions, _, rnn_states_actor = self.actor(obs, rnn_states_actor, masks, available_actions, deterministic)
         return actions, rnn_states_actor
 
+    # ---- one-launch rollout step (mappo_rollout_step) ----------------------------------------------------------
+    def can_fuse_step(self):
+        a, c = self.actor.desc, self.critic.desc
+        return (not a.recurrent and not c.recurrent and a.in_dim <= 64 and c.in_dim <= 64 and a.layer_N == c.layer_N
+                and a.use_relu == c.use_relu)
+
+    @torch.no_grad()
+    def collect_step_fused(self, buffer, step, pending=None, centralized=True, use_available_actions=False, deterministic=False):
+        """get_actions on the rows of step `step` AND (pending = (obs, rewards, dones) of the env step before it) the
+        insert of that env output into slot `step` — one kernel.  With `pending` the networks read the rows straight
+        from the env's output (strided views are fine) while other workgroups of the same launch copy them into
+        obs[step] / share_obs[step] / rewards[step-1] / masks[step]; without it they read the buffer slot.
+        Returns the fp32 actions view [N, M, 1], or None when `pending` does not have the expected device layout
+        (the caller then falls back to insert + collect_into)."""
+        N, M = buffer.n_rollout_threads, buffer.num_agents
+        R = N * M
+        D = self.actor.desc.in_dim
+        avail = buffer.available_actions[step].view(R, -1) if use_available_actions else None
+        insert = None
+        if pending is None:
+            obs_src = (buffer.obs[step], 0, 0)
+            share_src = (buffer.share_obs[step], 0, 0)
+            Mk = 0
+        else:
+            obs, rewards, dones = pending
+            ok = (torch.is_tensor(obs) and torch.is_tensor(rewards) and torch.is_tensor(dones) and obs.device == self.device
+                  and obs.dtype == torch.float32 and obs.dim() == 3 and obs.stride(2) == 1 and tuple(obs.shape) == (N, M, D)
+                  and rewards.device == self.device and rewards.dtype == torch.float32 and dones.device == self.device
+                  and dones.dtype == torch.bool and dones.dim() == 2)
+            if centralized:      # share row of (n, m) = the thread's agents side by side: needs them contiguous in the source
+                ok = ok and obs.stride(1) == D and self.critic.desc.in_dim == M * D
+            else:
+                ok = ok and self.critic.desc.in_dim == D
+            if not ok:
+                return None
+            if rewards.dim() == 3:
+                rewards = rewards[..., 0]
+            obs_src = (obs, obs.stride(0), obs.stride(1))
+            share_src = (obs, obs.stride(0), 0 if centralized else obs.stride(1))
+            Mk = M
+            insert = dict(obs_dst=buffer.obs[step], share_dst=buffer.share_obs[step], rewards=(rewards, rewards.stride(0), rewards.stride(1)),
+                          dones=(dones, dones.stride(0), dones.stride(1)), rew_dst=buffer.rewards[step - 1], mask_dst=buffer.masks[step],
+                          centralized=centralized)
+        ops.rollout_step(self.actor.flat, self.actor.desc, self.critic.flat, self.critic.desc, obs_src, share_src, Mk, R, avail,
+                         deterministic, self.actor._seed, step, self.actor._counter_dev, buffer.actions[step].view(R),
+                         buffer.action_log_probs[step].view(R), buffer.value_preds[step].view(R), insert)
+        return buffer.actions[step]
+
     # ---- fused rollout step (K8 subsumes K1): outputs land in buffer slot `step` ------------------------------
     @torch.no_grad()
     def collect_into(self, buffer, step, use_available_actions=False, deterministic=False):

@@ -7,33 +7,9 @@
 //   rewards[step]      <- rewards                               [N][M]
 //   masks[step+1]      <- 1 - done                              [N][M]
 // Pure HBM traffic: 4*(M*D + M*S + 2M) bytes per rollout thread, one thread per share_obs element (the largest output).
-#include "common.h"
+#include "insert_core.h"
 
-struct InsertArgs {
-  const float *obs;  int64_t obs_sn, obs_sm;       // element (n, m, d) at obs[n*obs_sn + m*obs_sm + d]
-  const float *rew;  int64_t rew_sn, rew_sm;       // element (n, m)    at rew[n*rew_sn + m*rew_sm]   (0 strides broadcast)
-  const uint8_t *done; int64_t done_sn, done_sm;   // bool bytes
-  float *obs_dst, *share_dst, *rew_dst, *mask_dst; // contiguous slots
-  int N, M, D, centralized;
-};
-
-__global__ __launch_bounds__(256) void insert_mpe_kernel(InsertArgs p) {
-  const int S = p.centralized ? p.M * p.D : p.D;
-  const int64_t total = (int64_t)p.N * p.M * S;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t nm = e / S;
-    const int j = (int)(e - nm * S);
-    const int n = (int)(nm / p.M), m = (int)(nm - (int64_t)n * p.M);
-    const int ms = p.centralized ? j / p.D : m, d = p.centralized ? j - ms * p.D : j;      // source agent / feature
-    const float v = p.obs[n * p.obs_sn + ms * p.obs_sm + d];
-    p.share_dst[e] = v;
-    if (!p.centralized || ms == m) p.obs_dst[nm * p.D + d] = v;                            // each obs element exactly once
-    if (j == 0) {
-      p.rew_dst[nm] = p.rew[n * p.rew_sn + m * p.rew_sm];
-      p.mask_dst[nm] = p.done[n * p.done_sn + m * p.done_sm] ? 0.f : 1.f;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void insert_mpe_kernel(InsertArgs p) { insert_mpe_body(p, blockIdx.x, gridDim.x); }
 
 extern "C" int mappo_insert_mpe(const float *obs, int64_t obs_stride_n, int64_t obs_stride_m, const float *rewards,
                                 int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones, int64_t done_stride_n,

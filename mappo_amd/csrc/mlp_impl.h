@@ -204,14 +204,15 @@ struct RowPrefetch {
 // commit_rows then routes it through an LDS staging area to reach the lane <-> sample layout.
 template <bool WIDE>
 __device__ __forceinline__ void prefetch_rows(RowPrefetch<WIDE> &pf, const float *__restrict__ x,
-                                              const int32_t *__restrict__ rows, int64_t base, int64_t B, int D, int lane) {
+                                              const int32_t *__restrict__ rows, int64_t base, int64_t B, int D, int lane,
+                                              int64_t x_sn = 0, int64_t x_sm = 0, int x_M = 0) {
   const int s = lane & 31, half = lane >> 5;
   pf.n_valid = (int)max((int64_t)0, min((int64_t)TS, B - base));
   pf.my_row = 0;
   const bool ok = s < pf.n_valid;
   if (ok) pf.my_row = rows ? rows[base + s] : (int)(base + s);
   constexpr int NV = WIDE ? TS : TS / 2;
-  pf.flat = rows == nullptr && pf.n_valid == TS && (D & 1) == 0 && (((uintptr_t)x) & 15) == 0;
+  pf.flat = rows == nullptr && x_M == 0 && pf.n_valid == TS && (D & 1) == 0 && (((uintptr_t)x) & 15) == 0;
   if (pf.flat) {
     const float4 *src4 = reinterpret_cast<const float4 *>(x + base * D);
     const int n4 = TS * D / 4;
@@ -222,7 +223,8 @@ __device__ __forceinline__ void prefetch_rows(RowPrefetch<WIDE> &pf, const float
     }
     return;
   }
-  const float *src = x + (int64_t)pf.my_row * D + half;
+  const int64_t row_off = x_M ? (int64_t)(pf.my_row / x_M) * x_sn + (int64_t)(pf.my_row % x_M) * x_sm : (int64_t)pf.my_row * D;
+  const float *src = x + row_off + half;
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
     pf.v[j] = 0.f;
@@ -497,12 +499,16 @@ struct FwdArgs {
   int deterministic;
   uint64_t seed, counter;
   const uint64_t *counter_dev;   // optional device word added to `counter` (lets a captured hipGraph draw fresh numbers)
+  // optional strided source rows (x_M > 0): sample i = (n, m) = (i / x_M, i % x_M) starts at x[n * x_sn + m * x_sm] — the
+  // env's output read in place (fused rollout step); x_M == 0: contiguous rows x[i * in_dim]
+  int64_t x_sn, x_sm;
+  int x_M;
 };
 
 // XW: 0 = in_dim <= 32, 1 = in_dim <= 64 (rows prefetched into registers), 2 = in_dim > 64 (K-chunked layer 1)
+// workgroup `bid` of `nb` workgroups that share the B rows (blockIdx / gridDim of a plain forward launch)
 template <bool RELU, int LN, int MODE, int XW>
-__global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
-  extern __shared__ __align__(16) float lds[];
+__device__ __forceinline__ void forward_body(const FwdArgs &p, float *lds, const int bid, const int nb) {
   constexpr bool WIDE = XW >= 1, XWIDE = XW == 2;
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
@@ -511,16 +517,16 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
   const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
   const uint32_t magic = (uint32_t)(0x100000000ull / (uint32_t)D) + 1u;
   const int64_t n_tiles = (p.B + TS - 1) / TS;
-  const int64_t tile_stride = (int64_t)gridDim.x * n_waves;
+  const int64_t tile_stride = (int64_t)nb * n_waves;
   const int64_t n_btiles = (n_tiles + n_waves - 1) / n_waves;    // the tile loop is uniform over the workgroup's waves
   RowPrefetch<WIDE> pf;
-  if (!XWIDE) prefetch_rows(pf, p.x, p.rows, ((int64_t)blockIdx.x * n_waves + wave) * TS, p.B, D, lane);   // under the staging
+  if (!XWIDE) prefetch_rows(pf, p.x, p.rows, ((int64_t)bid * n_waves + wave) * TS, p.B, D, lane, p.x_sn, p.x_sm, p.x_M);   // under the staging
   stage_all_weights<LN>(lds, m, p.params, o, p.desc);
   __syncthreads();
   float *tX = lds + m.tiles + wave * m.wave_stride;
   float *tH = tX + m.x_rows * TP;
   float *tZ = tH + (LN + 1) * HID * TP;
-  for (int64_t tb = blockIdx.x; tb < n_btiles; tb += gridDim.x) {
+  for (int64_t tb = bid; tb < n_btiles; tb += nb) {
     const int64_t tile = tb * n_waves + wave;
     const int64_t base = tile * TS;
     int n_valid;
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
       n_valid = pf.n_valid;
       commit_rows(tX, tH + ((4 - ((m.x_rows * TP) & 3)) & 3), pf, D, magic, lane, p.desc.use_feature_norm != 0);   // 16-B aligned staging
       wave_lds_sync();
-      prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane);
+      prefetch_rows(pf, p.x, p.rows, (tile + tile_stride) * TS, p.B, D, lane, p.x_sn, p.x_sm, p.x_M);
       tile_forward<RELU, LN>(lds, m, tX, tH, D, l31, half, st);
     } else {
       n_valid = (int)max((int64_t)0, min((int64_t)TS, p.B - base));
@@ -577,6 +583,30 @@ __global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
     }
     wave_lds_sync();
   }
+}
+
+template <bool RELU, int LN, int MODE, int XW>
+__global__ __launch_bounds__(256, 1) void mlp_forward_kernel(FwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  forward_body<RELU, LN, MODE, XW>(p, lds, blockIdx.x, gridDim.x);
+}
+
+// Fused rollout step (K7 + K8 + K1 in ONE launch): workgroups [0, nA) run the actor's get_actions, [nA, nA + nC) the
+// critic's get_values, the rest copy the env output the rows come from into the buffer slots (insert_core.h).  All
+// three read only their sources and write disjoint outputs, so there is nothing to order inside the launch.
+#include "insert_core.h"
+struct StepArgs {
+  FwdArgs a, c;
+  InsertArgs ins;
+  int nA, nC, nI;
+};
+template <bool RELU, int LN, int XWA, int XWC>
+__global__ __launch_bounds__(256, 1) void rollout_step_kernel(StepArgs s) {
+  extern __shared__ __align__(16) float lds[];
+  const int bid = blockIdx.x;
+  if (bid < s.nA) forward_body<RELU, LN, 1, XWA>(s.a, lds, bid, s.nA);
+  else if (bid < s.nA + s.nC) forward_body<RELU, LN, 0, XWC>(s.c, lds, bid - s.nA, s.nC);
+  else insert_mpe_body(s.ins, bid - s.nA - s.nC, s.nI);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1204,7 +1234,7 @@ template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 2>(bool, dim3, dim3, size_t, hi
 template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 3>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
 #endif
 
-#ifdef MLP_TU_MAIN
+#if defined(MLP_TU_MAIN) || defined(MLP_TU_STEP)
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1232,6 +1262,90 @@ static int fit_waves(const mappo_net_desc &d, int want) {
   return nw;
 }
 
+#endif
+
+#ifdef MLP_TU_STEP
+// ---- fused rollout step (rollout_step_kernel): translation unit mlp_step.hip --------------------------------------
+template <bool R, int L, int XA, int XC>
+static int step_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const StepArgs &a) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)rollout_step_kernel<R, L, XA, XC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_DYN_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("rollout_step: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_ACT, (rollout_step_kernel<R, L, XA, XC>), grid, block, lds_bytes, st, a);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+static int step_dispatch(int xa, int xc, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const StepArgs &a) {
+  if (xa == 0) return xc == 0 ? step_launch<R, L, 0, 0>(grid, block, lds_bytes, st, a) : step_launch<R, L, 0, 1>(grid, block, lds_bytes, st, a);
+  return xc == 0 ? step_launch<R, L, 1, 0>(grid, block, lds_bytes, st, a) : step_launch<R, L, 1, 1>(grid, block, lds_bytes, st, a);
+}
+
+extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_desc *actor_desc, const float *critic_params,
+                                  const mappo_net_desc *critic_desc, const float *obs, int64_t obs_stride_n, int64_t obs_stride_m,
+                                  const float *share_obs, int64_t share_stride_n, int64_t share_stride_m, int32_t M, int64_t B,
+                                  const float *avail, int32_t deterministic, uint64_t seed, uint64_t counter,
+                                  const uint64_t *counter_dev, float *actions, float *logp, float *values, float *obs_dst,
+                                  float *share_dst, const float *rewards, int64_t rew_stride_n, int64_t rew_stride_m,
+                                  const uint8_t *dones, int64_t done_stride_n, int64_t done_stride_m, float *rew_dst,
+                                  float *mask_dst, int32_t centralized, mappo_stream_t stream) {
+  if (int rc = check_desc(actor_desc, "rollout_step")) return rc;
+  if (int rc = check_desc(critic_desc, "rollout_step")) return rc;
+  MAPPO_REQUIRE(actor_desc->in_dim <= MAXD && critic_desc->in_dim <= MAXD, "rollout_step: in_dim > %d goes through the separate kernels", MAXD);
+  MAPPO_REQUIRE(actor_desc->layer_N == critic_desc->layer_N && actor_desc->use_relu == critic_desc->use_relu,
+                "rollout_step: actor and critic must share layer_N and the activation");
+  MAPPO_REQUIRE(critic_desc->out_dim == 1, "rollout_step: critic out_dim must be 1");
+  MAPPO_REQUIRE(actor_params && critic_params && obs && share_obs && actions && logp && values && B > 0 && M >= 0, "rollout_step: bad arguments");
+  MAPPO_REQUIRE(M > 0 || !obs_dst, "rollout_step: the fused insert needs the (thread, agent) row layout (M > 0)");
+  MAPPO_REQUIRE(!obs_dst || (share_dst && rewards && dones && rew_dst && mask_dst && B % M == 0), "rollout_step: incomplete insert arguments");
+  MAPPO_CLEAR_STICKY();
+  const int64_t n_tiles = (B + TS - 1) / TS;
+  const int want = n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1);
+  int nw = fit_waves(*actor_desc, want);
+  const int nwc = fit_waves(*critic_desc, want);
+  nw = nw < nwc ? nw : nwc;
+  StepArgs s = {};
+  s.a.params = actor_params; s.a.x = obs; s.a.avail = avail; s.a.actions = actions; s.a.logp = logp; s.a.desc = *actor_desc; s.a.B = B;
+  s.a.deterministic = deterministic; s.a.seed = seed; s.a.counter = counter; s.a.counter_dev = counter_dev;
+  s.a.x_sn = obs_stride_n; s.a.x_sm = obs_stride_m; s.a.x_M = M;
+  s.a.off = net_offsets(s.a.desc); s.a.map = lds_map(s.a.desc, nw);
+  s.c.params = critic_params; s.c.x = share_obs; s.c.out = values; s.c.desc = *critic_desc; s.c.B = B;
+  s.c.x_sn = share_stride_n; s.c.x_sm = share_stride_m; s.c.x_M = M;
+  s.c.off = net_offsets(s.c.desc); s.c.map = lds_map(s.c.desc, nw);
+  const int totA = s.a.map.total, totC = s.c.map.total;
+  const size_t lds_bytes = (size_t)(totA > totC ? totA : totC) * sizeof(float);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "rollout_step: needs %zu B of LDS", lds_bytes);
+  int64_t nb = (n_tiles + nw - 1) / nw;
+  if (nb > NUM_CU / 2) nb = NUM_CU / 2;
+  s.nA = (int)nb; s.nC = (int)nb; s.nI = 0;
+  if (obs_dst) {
+    InsertArgs &i = s.ins;
+    i.obs = obs; i.obs_sn = obs_stride_n; i.obs_sm = obs_stride_m; i.rew = rewards; i.rew_sn = rew_stride_n; i.rew_sm = rew_stride_m;
+    i.done = dones; i.done_sn = done_stride_n; i.done_sm = done_stride_m; i.obs_dst = obs_dst; i.share_dst = share_dst;
+    i.rew_dst = rew_dst; i.mask_dst = mask_dst; i.N = (int)(B / M); i.M = M; i.D = actor_desc->in_dim; i.centralized = centralized;
+    const int64_t total = B * (centralized ? (int64_t)M * i.D : i.D);
+    int64_t ni = (total + 2047) / 2048;                  // ~8 elements per thread
+    s.nI = (int)(ni > 64 ? 64 : ni);
+  }
+  dim3 grid((unsigned)(s.nA + s.nC + s.nI)), block(WAVE * nw);
+  const int xa = actor_desc->in_dim > 32 ? 1 : 0, xc = critic_desc->in_dim > 32 ? 1 : 0;
+  const bool relu = actor_desc->use_relu != 0;
+  int rc;
+  switch (actor_desc->layer_N) {
+    case 0: rc = relu ? step_dispatch<true, 0>(xa, xc, grid, block, lds_bytes, as_stream(stream), s) : step_dispatch<false, 0>(xa, xc, grid, block, lds_bytes, as_stream(stream), s); break;
+    case 1: rc = relu ? step_dispatch<true, 1>(xa, xc, grid, block, lds_bytes, as_stream(stream), s) : step_dispatch<false, 1>(xa, xc, grid, block, lds_bytes, as_stream(stream), s); break;
+    default: rc = relu ? step_dispatch<true, 2>(xa, xc, grid, block, lds_bytes, as_stream(stream), s) : step_dispatch<false, 2>(xa, xc, grid, block, lds_bytes, as_stream(stream), s); break;
+  }
+  if (rc) return rc;
+  MAPPO_CHECK_LAUNCH("rollout_step");
+  return MAPPO_OK;
+}
+#endif
+
+#ifdef MLP_TU_MAIN
 template <int MODE>
 static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) {
   MAPPO_CLEAR_STICKY();

@@ -137,6 +137,29 @@ def actor_act(params, desc, obs, avail, B, deterministic, seed, counter, actions
     _lib.check(rc, "mappo_actor_act")
 
 
+def rollout_step(actor_params, actor_desc, critic_params, critic_desc, obs, share_obs, M, B, avail, deterministic, seed, counter,
+                 counter_dev, actions, logp, values, insert=None):
+    """Fused rollout step.  obs / share_obs: (tensor, stride_n, stride_m) row sources (strides in elements; M == 0 means
+    contiguous [B][D] and the strides are ignored).  insert: None or dict(obs_dst, share_dst, rewards=(tensor, sn, sm),
+    dones=(tensor, sn, sm), rew_dst, mask_dst, centralized) — the env output `obs` comes from is copied into those slots."""
+    ot, osn, osm = obs
+    st, ssn, ssm = share_obs
+    if insert is None:
+        ins = (None, None, None, 0, 0, None, 0, 0, None, None, 0)
+    else:
+        rt, rsn, rsm = insert["rewards"]
+        dt, dsn, dsm = insert["dones"]
+        ins = (C.c_void_p(insert["obs_dst"].data_ptr()), C.c_void_p(insert["share_dst"].data_ptr()), C.c_void_p(rt.data_ptr()), int(rsn), int(rsm),
+               C.c_void_p(dt.data_ptr()), int(dsn), int(dsm), C.c_void_p(insert["rew_dst"].data_ptr()), C.c_void_p(insert["mask_dst"].data_ptr()),
+               int(bool(insert["centralized"])))
+    rc = _lib.load().mappo_rollout_step(_ptr(actor_params), C.byref(actor_desc), _ptr(critic_params), C.byref(critic_desc),
+                                        C.c_void_p(ot.data_ptr()), int(osn), int(osm), C.c_void_p(st.data_ptr()), int(ssn), int(ssm), int(M), int(B),
+                                        _ptr(avail, allow_none=True), int(bool(deterministic)), int(seed) & (2 ** 64 - 1),
+                                        int(counter) & (2 ** 64 - 1), _ptr(counter_dev, torch.int64, allow_none=True), _ptr(actions),
+                                        _ptr(logp), _ptr(values), *ins, _stream())
+    _lib.check(rc, "mappo_rollout_step")
+
+
 def mlp_backward_slabs(B):
     return int(_lib.load().mappo_mlp_backward_slabs(int(B)))
 

@@ -18,6 +18,7 @@ class MPERunner(Runner):
         super(MPERunner, self).__init__(config)
         self._onehot = None
         self._rollout_graph = None          # None -> "warm" -> CUDAGraph
+        self._fuse_step = bool(getattr(self.all_args, "fuse_rollout_step", True))
         self._use_graph = bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False)) \
             and config.get("dist_group") is None
 
@@ -58,11 +59,27 @@ class MPERunner(Runner):
     def _rollout_body(self):
         infos = None
         self.trainer.policy.actor._counter_dev.add_(self.episode_length)   # fresh sampling stream per (replayed) episode
+        fuse = self._fuse_step and self.trainer.policy.can_fuse_step()
+        pending = None                     # env output of the previous step, not yet in the buffer (fused path)
         for step in range(self.episode_length):
+            if fuse:
+                # one launch: insert(step - 1) + collect(step) (mappo_rollout_step); same buffer contents as the plain loop
+                actions = self.trainer.policy.collect_step_fused(self.buffer, step, pending, self.use_centralized_V)
+                if actions is None:        # env output without the expected device layout: plain insert, then collect
+                    self.insert(pending + (None,) * 6)
+                    actions = self.trainer.policy.collect_step_fused(self.buffer, step, None, self.use_centralized_V)
+                elif pending is not None:
+                    self.buffer.step = step % self.episode_length
+                actions_env = self._actions_env(actions)
+                obs, rewards, dones, infos = self.envs.step(actions_env)
+                pending = (obs, rewards, dones)
+                continue
             values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env = self.collect(step)
             obs, rewards, dones, infos = self.envs.step(actions_env)
             data = obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic
             self.insert(data)
+        if fuse:
+            self.insert(pending + (None,) * 6)      # the last env output: plain insert kernel
         self.compute()
         return infos
 
@@ -115,6 +132,17 @@ class MPERunner(Runner):
         return b.value_preds[step], actions, b.action_log_probs[step], rnn_states, rnn_states_critic, actions_env
 
     # mpe_runner.py:125-139
+    def _actions_env(self, actions):
+        b = self.buffer
+        if not getattr(self.envs, "consumes_actions", True):     # synthetic envs ignore the actions: skip the one-hot
+            return None
+        if self._onehot is None:
+            self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
+        actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]       # np.eye(n)[actions]
+        if getattr(self.envs, "needs_host_actions", False):
+            actions_env = _t2n(actions_env)
+        return actions_env
+
     def insert(self, data):
         obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic = data
         b = self.buffer

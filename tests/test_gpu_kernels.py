@@ -587,3 +587,40 @@ def test_insert_mpe_kernel(ops, centralized):
     np.testing.assert_array_equal(sd.cpu().numpy(), share_ref.cpu().numpy())
     np.testing.assert_array_equal(rd.cpu().numpy(), rew.cpu().numpy())
     np.testing.assert_array_equal(md.cpu().numpy(), (~dones).float().view(N, M, 1).cpu().numpy())
+
+
+@pytest.mark.parametrize("centralized", [True, False])
+def test_rollout_step_fused_matches_separate_launches(ops, centralized):
+    """mappo_rollout_step (one launch: insert of the env output + get_actions + get_values, rows read in place from a
+    strided env block) == mappo_insert_mpe, then mappo_actor_act / mappo_mlp_forward on the buffer slots, bit for bit."""
+    N, M, D, A = 70, 3, 18, 5
+    R = N * M
+    g = torch.Generator(device="cuda").manual_seed(1)
+    blk = torch.randn(N, M * D + 1, device="cuda", generator=g)
+    obs = blk[:, :M * D].view(N, M, D)
+    rew = blk[:, M * D:].view(N, 1, 1).expand(N, M, 1)[..., 0]
+    dones = torch.rand(N, M, device="cuda", generator=g) > 0.5
+    S = M * D if centralized else D
+    da, dc = ops.net_desc(D, A), ops.net_desc(S, 1)
+    pa = torch.randn(ops.net_param_count(da), device="cuda", generator=g) * 0.2
+    pc = torch.randn(ops.net_param_count(dc), device="cuda", generator=g) * 0.2
+    # reference: separate launches
+    od, sd, rd, md = (torch.empty(s, device="cuda") for s in ((N, M, D), (N, M, S), (N, M, 1), (N, M, 1)))
+    ops.insert_mpe(obs, rew, dones, od, sd, rd, md, centralized)
+    act0, lp0, v0 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, 1, device="cuda")
+    ops.actor_act(pa, da, od.view(R, D), None, R, False, 1234, 7, act0, lp0)
+    ops.mlp_forward(pc, dc, sd.view(R, S), None, R, v0)
+    # fused
+    od1, sd1, rd1, md1 = (torch.full(s, float("nan"), device="cuda") for s in ((N, M, D), (N, M, S), (N, M, 1), (N, M, 1)))
+    act1, lp1, v1 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    ins = dict(obs_dst=od1, share_dst=sd1, rewards=(rew, rew.stride(0), rew.stride(1)), dones=(dones, dones.stride(0), dones.stride(1)),
+               rew_dst=rd1, mask_dst=md1, centralized=centralized)
+    ops.rollout_step(pa, da, pc, dc, (obs, obs.stride(0), obs.stride(1)), (obs, obs.stride(0), 0 if centralized else obs.stride(1)), M, R,
+                     None, False, 1234, 7, None, act1, lp1, v1, ins)
+    for a_, b_ in ((od, od1), (sd, sd1), (rd, rd1), (md, md1), (act0, act1), (lp0, lp1), (v0.view(R), v1)):
+        np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+    # without the insert, reading the (contiguous) slots
+    act2, lp2, v2 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    ops.rollout_step(pa, da, pc, dc, (od, 0, 0), (sd, 0, 0), 0, R, None, False, 1234, 7, None, act2, lp2, v2, None)
+    for a_, b_ in ((act0, act2), (lp0, lp2), (v0.view(R), v2)):
+        np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
