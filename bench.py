@@ -142,7 +142,8 @@ def install_timer(timer):
     for name, kernel, label in (("ppo_loss_fwd_bwd", "ppo_loss", "ppo_loss"), ("mlp_backward", "mlp_bwd", "mlp_backward"),
                                 ("actor_update", "mlp_bwd", "actor_update"), ("critic_update", "mlp_bwd", "critic_update"),
                                 ("mlp_forward", "mlp_fwd", "mlp_forward"), ("gae_scan", "gae", "gae_scan"),
-                                ("slab_reduce", "slab_reduce", "slab_reduce"), ("actor_act", "act", "actor_act")):
+                                ("slab_reduce", "slab_reduce", "slab_reduce"), ("actor_act", "act", "actor_act"),
+                                ("rollout_step", "act", "rollout_step")):
         orig = getattr(ops, name)
 
         def wrapped(*a, _orig=orig, _k=kernel, _l=label, **kw):
@@ -239,7 +240,8 @@ def main():
     # the hot kernels carries HIP events (hipGraph replays cannot be instrumented from the host) ----
     graph_flags = (runner._use_graph, runner.trainer._use_graph)
     runner._use_graph = runner.trainer._use_graph = False
-    labels = ["actor_update", "critic_update", "mlp_forward", "gae_scan", "slab_reduce", "actor_act", "ppo_loss", "mlp_backward"]
+    labels = ["actor_update", "critic_update", "rollout_step", "mlp_forward", "gae_scan", "slab_reduce", "actor_act", "ppo_loss",
+              "mlp_backward"]
     timer.active = set(labels)
     for i in range(2):
         runner.run_episode(0, 1)
@@ -258,11 +260,11 @@ def main():
         us = kern["critic_update"]
         flops = S * 6 * macs_critic                          # forward + dW + dX, 2 flop per MAC
         achieved = flops / (us * 1e-6) / 1e12
-        roofline = dict(bound="mfma", kernel="mlp_update_kernel<relu, layer_N=1, HEAD=critic, wide>", achieved=achieved,
+        roofline = dict(bound="mfma", kernel="mlp_update2_kernel<relu, layer_N=1, HEAD=critic, wide>", achieved=achieved,
                         peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None,
                         flops_per_launch=flops, launch_us=us,
-                        note="algorithmic flops = 6 x forward MACs per sample (forward, dW, dX); the kernel also recomputes the "
-                             "forward (not counted)")
+                        note="algorithmic flops = 6 x forward MACs per sample (forward, dW, dX; SURVEY.md 8d); the kernel issues "
+                             "fewer: the input layer needs no dX (feature-norm gradients come from the dW products)")
     loss_roof = ppo_loss_roofline(runner, timer, A)
     out = dict(metric="agent-steps/sec (collect+GAE+PPO), MPE simple_spread 3-agent", value=value, unit="agent-steps/s",
                n_gpus=world, steps=ns.steps, warmup=ns.warmup, ms_per_step=1e3 * dt / ns.steps, higher_is_better=True,

@@ -248,6 +248,13 @@ int mappo_clip_adam(float *params, const float *grad, float *exp_avg, float *exp
                     const float *opt_hyper, int32_t *opt_step, float *grad_norms,
                     double *norm_acc /*[n_seg] running sums of the norms, or NULL*/, void *workspace,
                     mappo_stream_t stream);
+/* mappo_slab_reduce + mappo_clip_adam in two launches instead of four (single-process training: nothing has to happen
+ * between the reduction and the optimizer step).  Same arithmetic; the squared-norm partials are taken per 128
+ * entries inside the reduction.  workspace: mappo_optim_workspace_bytes(P) bytes. */
+int mappo_reduce_clip_adam(const float *slabs, int32_t n_slabs, int64_t slab_stride, float *params, float *grad /*out*/,
+                           float *exp_avg, float *exp_avg_sq, const int64_t *seg_bounds /*host [n_seg+1]*/, int32_t n_seg,
+                           const float *opt_hyper, int32_t *opt_step, float *grad_norms, double *norm_acc /*or NULL*/,
+                           void *workspace, mappo_stream_t stream);
 
 /* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel carries the two hipEvent_t
  * handles (hipExtLaunchKernelGGL: start / stop of that dispatch on its own stream); the hook disarms after one use. */

@@ -16,6 +16,7 @@ when num_mini_batch == 1, where the permutation only reorders the terms of sums)
 loop (the reference syncs 3x per minibatch, r_mappo.py:207-209): statistics accumulate on the device and
 are read once at the end of train()."""
 import numpy as np
+import os
 import torch
 
 from mappo_amd import ops
@@ -95,6 +96,9 @@ class R_MAPPO():
                                   self._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
             if self._dist is not None:
                 self._dist.all_reduce_sum_(self._mb_moments)
+        # (ValueNorm.update and the loss statistics are tiny kernels that nothing waits for immediately; forking them to a
+        # side stream next to the update kernels measured SLOWER inside the captured hipGraph — train 1.96 ms vs 1.69 ms
+        # at config 2 — so the chain stays on one stream.)
         if self._use_valuenorm:
             ops.valuenorm_update(vn_state, self._mb_moments, self.value_normalizer.beta)
         n_slabs = ops.mlp_backward_slabs(B)
@@ -148,14 +152,18 @@ class R_MAPPO():
             if update_actor:
                 ops.mlp_backward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, dlogits, slabs, P, 0)
             ops.mlp_backward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, dvalues, slabs, P, pol.seg_bounds[1])
-        ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
-        if self._dist is not None:
-            self._dist.all_reduce_sum_(pol.flat_grad)          # C1: one flat fp32 all-reduce per minibatch
         if update_actor != self._actor_enabled:                  # torch >= 2: grad None => Adam skips the actor
             pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
             self._actor_enabled = update_actor
-        ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper,
-                      pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
+        if self._dist is None:
+            # single process: reduction + clip + Adam in two launches
+            ops.reduce_clip_adam(slabs, n_slabs, P, pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds,
+                                 pol.opt_hyper, pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
+        else:
+            ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
+            self._dist.all_reduce_sum_(pol.flat_grad)          # C1: one flat fp32 all-reduce per minibatch
+            ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper,
+                          pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
 
     _actor_slabs_clean = True
     _actor_enabled = True

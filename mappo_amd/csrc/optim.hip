@@ -108,8 +108,94 @@ __global__ __launch_bounds__(OPT_BLOCK) void adam_kernel(float *__restrict__ par
   params[i] = p; m[i] = mi; v[i] = vi;
 }
 
+// ---- two-launch variant of slab_reduce + clip_adam (the per-update tail of the PPO loop is launch-bound: every
+// kernel here runs a few microseconds, so the launches themselves are what it costs) --------------------------------
+// (1) slab_reduce that also leaves the squared-norm partial of its 128 gradient entries;
+// (2) norm finalisation + Adam in one kernel (see norm_adam_kernel).
+__global__ __launch_bounds__(SLAB_BLOCK) void slab_reduce_sq_kernel(const float *__restrict__ slabs, int n_slabs, int64_t stride,
+                                                                   int64_t P, float *__restrict__ grad, double *__restrict__ partials,
+                                                                   const float *__restrict__ hyper, int32_t *step, int n_seg) {
+  __shared__ double smem[16];
+  if (blockIdx.x == 0 && threadIdx.x < n_seg && hyper[threadIdx.x * 8 + 7] != 0.f) step[threadIdx.x] += 1;   // Adam step of enabled segments
+  const int64_t p = (int64_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
+  float g = 0.f;
+  if (p < P) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 16 <= n_slabs; s += 16) {
+      float v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = slabs[(size_t)(s + j) * stride + p];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j & 3] += v[j];          // same association as slab_reduce_kernel
+    }
+    for (; s < n_slabs; ++s) acc[0] += slabs[(size_t)s * stride + p];
+    g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    grad[p] = g;
+  }
+  double v[1] = {(double)g * (double)g};
+  block_sum<1>(v, smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+// One 256-thread workgroup per 256 parameters (never straddles a segment).  Every workgroup finalises the norm of ITS
+// segment itself (a few dozen partials + two pow()s: redundant across workgroups, but in parallel and without a
+// separate launch), then applies Adam to its slice.  The step counters were advanced by slab_reduce_sq_kernel's first
+// workgroup (a kernel boundary orders that increment before every read here); workgroup 0 also publishes the norms.
+__global__ __launch_bounds__(OPT_BLOCK) void norm_adam_kernel(const double *__restrict__ partials, SegBounds sb,
+                                                             const float *__restrict__ hyper, const int32_t *__restrict__ step,
+                                                             float *__restrict__ grad_norms, double *__restrict__ norm_acc,
+                                                             float *__restrict__ params, const float *__restrict__ grad,
+                                                             float *__restrict__ m, float *__restrict__ v) {
+  __shared__ double smem[16];
+  __shared__ float ws[4];
+  const int64_t i = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x;
+  const int s = seg_of(sb, (int64_t)blockIdx.x * OPT_BLOCK);
+  const float gi = grad[i], pi = params[i], mi0 = m[i], vi0 = v[i];      // in flight under the norm reduction
+  const int n_seg_pub = (blockIdx.x == 0) ? sb.n : 1;                   // workgroup 0 walks all segments to publish their norms
+  for (int k = 0; k < n_seg_pub; ++k) {
+    const int sk = (blockIdx.x == 0) ? (k == 0 ? s : (k <= s ? k - 1 : k)) : s;      // own segment first
+    const int b0 = (int)(sb.b[sk] / SLAB_BLOCK), b1 = (int)(sb.b[sk + 1] / SLAB_BLOCK);
+    double acc[1] = {0.0};
+    for (int b = b0 + threadIdx.x; b < b1; b += blockDim.x) acc[0] += partials[b];
+    block_sum<1>(acc, smem);
+    if (threadIdx.x == 0) {
+      const float *h = hyper + sk * 8;
+      const float norm = (float)sqrt(acc[0]);
+      if (blockIdx.x == 0) {
+        grad_norms[sk] = norm;
+        if (norm_acc) norm_acc[sk] += (double)norm;
+      }
+      if (k == 0) {
+        float coef = 1.f;
+        if (h[6] != 0.f) coef = fminf(h[5] / (norm + 1e-6f), 1.f);
+        const int t = step[sk];
+        const double bc1 = 1.0 - pow((double)h[1], (double)t);
+        const double bc2 = 1.0 - pow((double)h[2], (double)t);
+        ws[0] = coef;
+        ws[1] = (float)((double)h[0] / (bc1 > 0.0 ? bc1 : 1.0));
+        ws[2] = (float)sqrt(bc2 > 0.0 ? bc2 : 1.0);
+        ws[3] = h[7] != 0.f ? 1.f : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  if (ws[3] == 0.f) return;
+  const float *h = hyper + s * 8;
+  const float b1 = h[1], b2 = h[2], eps = h[3], wd = h[4];
+  float g = gi * ws[0];
+  float pp = pi;
+  if (wd != 0.f) g = g + wd * pp;
+  float mi = mi0, vi = vi0;
+  mi = mi + (g - mi) * (1.f - b1);
+  vi = vi * b2 + g * g * (1.f - b2);
+  const float denom = sqrtf(vi) / ws[2] + eps;
+  pp = pp - ws[1] * (mi / denom);
+  params[i] = pp; m[i] = mi; v[i] = vi;
+}
+
 extern "C" int64_t mappo_optim_workspace_bytes(int64_t P) {
-  const int64_t nblk = (P + OPT_BLOCK - 1) / OPT_BLOCK;
+  const int64_t nblk = (P + SLAB_BLOCK - 1) / SLAB_BLOCK;       // mappo_reduce_clip_adam keeps one partial per 128 entries
   return nblk * (int64_t)sizeof(double) + OPT_MAX_SEG * 4 * (int64_t)sizeof(float) + 64;
 }
 
@@ -150,5 +236,33 @@ extern "C" int mappo_clip_adam(float *params, const float *grad, float *exp_avg,
                      (const float *)seg_ws);
   PROF_END(MAPPO_PROF_ADAM, st);
   MAPPO_CHECK_LAUNCH("clip_adam");
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_reduce_clip_adam(const float *slabs, int32_t n_slabs, int64_t slab_stride, float *params, float *grad,
+                                      float *exp_avg, float *exp_avg_sq, const int64_t *seg_bounds, int32_t n_seg,
+                                      const float *opt_hyper, int32_t *opt_step, float *grad_norms, double *norm_acc,
+                                      void *workspace, mappo_stream_t stream) {
+  MAPPO_REQUIRE(slabs && params && grad && exp_avg && exp_avg_sq && seg_bounds && opt_hyper && opt_step && grad_norms && workspace,
+                "reduce_clip_adam: null pointer");
+  MAPPO_REQUIRE(n_seg >= 1 && n_seg <= OPT_MAX_SEG && n_slabs > 0, "reduce_clip_adam: n_seg=%d n_slabs=%d", n_seg, n_slabs);
+  SegBounds sb;
+  sb.n = n_seg;
+  for (int s = 0; s <= n_seg; ++s) {
+    MAPPO_REQUIRE(seg_bounds[s] % OPT_BLOCK == 0 && (s == 0 || seg_bounds[s] > seg_bounds[s - 1]),
+                  "reduce_clip_adam: segment bounds must be increasing multiples of %d", OPT_BLOCK);
+    sb.b[s] = seg_bounds[s];
+  }
+  MAPPO_REQUIRE(seg_bounds[0] == 0, "reduce_clip_adam: seg_bounds[0] must be 0");
+  const int64_t P = seg_bounds[n_seg];
+  MAPPO_REQUIRE(slab_stride >= P, "reduce_clip_adam: slab_stride < P");
+  const int nblk = (int)(P / SLAB_BLOCK);             // P is a multiple of 256: mappo_optim_workspace_bytes(P) covers P/128 doubles
+  double *partials = (double *)workspace;
+  hipStream_t st = as_stream(stream);
+  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_sq_kernel, dim3(nblk), dim3(SLAB_BLOCK), 0, st, slabs, (int)n_slabs, slab_stride, P,
+              grad, partials, opt_hyper, opt_step, (int)n_seg);
+  PROF_LAUNCH(MAPPO_PROF_ADAM, norm_adam_kernel, dim3((unsigned)(P / OPT_BLOCK)), dim3(OPT_BLOCK), 0, st, (const double *)partials, sb,
+              opt_hyper, (const int32_t *)opt_step, grad_norms, norm_acc, params, (const float *)grad, exp_avg, exp_avg_sq);
+  MAPPO_CHECK_LAUNCH("reduce_clip_adam");
   return MAPPO_OK;
 }

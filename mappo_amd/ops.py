@@ -311,6 +311,17 @@ def clip_adam(params, grad, exp_avg, exp_avg_sq, seg_bounds, opt_hyper, opt_step
     _lib.check(rc, "mappo_clip_adam")
 
 
+def reduce_clip_adam(slabs, n_slabs, slab_stride, params, grad, exp_avg, exp_avg_sq, seg_bounds, opt_hyper, opt_step, grad_norms,
+                     workspace, norm_acc=None):
+    """slab_reduce + clip_adam in two launches (single-process training)."""
+    n_seg = len(seg_bounds) - 1
+    arr = (C.c_int64 * (n_seg + 1))(*[int(b) for b in seg_bounds])
+    rc = _lib.load().mappo_reduce_clip_adam(_ptr(slabs), int(n_slabs), int(slab_stride), _ptr(params), _ptr(grad), _ptr(exp_avg),
+                                            _ptr(exp_avg_sq), arr, n_seg, _ptr(opt_hyper), _ptr(opt_step, torch.int32), _ptr(grad_norms),
+                                            _ptr(norm_acc, torch.float64, allow_none=True), _ptr(workspace, torch.uint8), _stream())
+    _lib.check(rc, "mappo_reduce_clip_adam")
+
+
 def selftest_mfma(A, Bm, D):
     rc = _lib.load().mappo_selftest_mfma(_ptr(A), _ptr(Bm), _ptr(D), _stream())
     _lib.check(rc, "mappo_selftest_mfma")

@@ -624,3 +624,32 @@ def test_rollout_step_fused_matches_separate_launches(ops, centralized):
     ops.rollout_step(pa, da, pc, dc, (od, 0, 0), (sd, 0, 0), 0, R, None, False, 1234, 7, None, act2, lp2, v2, None)
     for a_, b_ in ((act0, act2), (lp0, lp2), (v0.view(R), v2)):
         np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+
+
+def test_reduce_clip_adam_matches_slab_reduce_then_clip_adam(ops):
+    """mappo_reduce_clip_adam (2 launches) == mappo_slab_reduce + mappo_clip_adam (4 launches): the reduced gradient bit
+    for bit, norms / parameters / moments to fp32 rounding of the norm (its double partial sums associate differently)."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    Pa, Pc, n_slabs = 6144, 8448, 37
+    P = Pa + Pc
+    slabs = torch.randn(n_slabs, P, device="cuda", generator=g) * 0.05
+    hyper = torch.tensor([[7e-4, 0.9, 0.999, 1e-5, 0.0, 10.0, 1.0, 1.0], [5e-4, 0.9, 0.999, 1e-5, 0.0, 0.5, 1.0, 1.0]],
+                         dtype=torch.float32).cuda()
+    p0 = torch.randn(P, device="cuda", generator=g)
+    out = []
+    for fused in (False, True):
+        params = p0.clone(); m = torch.zeros(P, device="cuda"); v = torch.zeros(P, device="cuda")
+        step = torch.zeros(2, dtype=torch.int32, device="cuda"); norms = torch.zeros(2, device="cuda")
+        acc = torch.zeros(2, dtype=torch.float64, device="cuda"); grad = torch.empty(P, device="cuda")
+        ws = ops.optim_workspace(P, params.device)
+        for it in range(3):
+            if fused:
+                ops.reduce_clip_adam(slabs, n_slabs, P, params, grad, m, v, [0, Pa, P], hyper, step, norms, ws, norm_acc=acc)
+            else:
+                ops.slab_reduce(slabs, n_slabs, P, P, grad)
+                ops.clip_adam(params, grad, m, v, [0, Pa, P], hyper, step, norms, ws, norm_acc=acc)
+        out.append([t.cpu().numpy() for t in (grad, params, m, v, norms, acc, step)])
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][6], out[1][6])
+    for a_, b_ in zip(out[0][1:6], out[1][1:6]):
+        np.testing.assert_allclose(a_, b_, rtol=2e-6, atol=1e-7)
