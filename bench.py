@@ -182,8 +182,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    force_dp = os.environ.get("MAPPO_BENCH_FORCE_DP") == "1"     # rehearsal of the data-parallel code path on ONE rank
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -199,7 +202,7 @@ def main():
     M, D, A = 3, 18, 5
     torch.manual_seed(args.seed)                           # identical initial replicas on every rank
     env = SyntheticMPEEnv(args.n_rollout_threads, M, D, A, args.episode_length, seed=1 + rank, device=device)
-    dp = DataParallel() if world > 1 else None
+    dp = DataParallel() if (world > 1 or force_dp) else None
     runner = MPERunner(dict(all_args=args, envs=env, eval_envs=None, num_agents=M, device=device, run_dir=None, dist_group=dp))
     timer = KernelTimer()
     install_timer(timer)
@@ -288,8 +291,9 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -54,6 +54,7 @@ class R_MAPPO():
         self._use_graph = bool(getattr(args, "use_hip_graph", True))
         self._concurrent_update = bool(getattr(args, "concurrent_update", False))
         self._graphs = {}
+        self._dp_graphs = {}                       # data-parallel runs: hipGraphs of the collective-free segments
 
         assert (self._use_popart and self._use_valuenorm) == False, \
             "self._use_popart and self._use_valuenorm can not be set True simultaneously"
@@ -84,11 +85,38 @@ class R_MAPPO():
         return self._buf(name, (int(nbytes),), torch.uint8)
 
     # ---- one PPO update on rows of flat source arrays (r_mappo.py:91-164) -------------------------------------
-    def _update(self, src, rows, B, update_actor=True, moments_ready=False):
+    def _update(self, src, rows, B, update_actor=True, moments_ready=False, part="all"):
+        """part (data-parallel runs only): "kernels" = everything up to the local gradient (no collective inside: this is
+        the segment the data-parallel trainer captures into a hipGraph), "optim" = gradient all-reduce + clip + Adam."""
         pol = self.policy
         A = pol.actor.n_actions
         lib = ops._lib.load()
         vn_state = self.value_normalizer.state if self._use_valuenorm else None
+        n_slabs = ops.mlp_backward_slabs(B)
+        P = pol.n_flat
+        if part != "optim":
+            slabs = self._update_kernels(src, rows, B, update_actor, moments_ready, vn_state, n_slabs, P)
+        else:
+            slabs = self._buf("slabs", (n_slabs, P))
+        if update_actor != self._actor_enabled and part != "kernels":      # torch >= 2: grad None => Adam skips the actor
+            pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
+            self._actor_enabled = update_actor
+        if self._dist is None:
+            # single process: reduction + clip + Adam in two launches
+            ops.reduce_clip_adam(slabs, n_slabs, P, pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds,
+                                 pol.opt_hyper, pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
+            return
+        if part != "optim":
+            ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
+        if part != "kernels":
+            self._dist.all_reduce_sum_(pol.flat_grad)          # C1: one flat fp32 all-reduce per minibatch
+            ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper,
+                          pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
+
+    def _update_kernels(self, src, rows, B, update_actor, moments_ready, vn_state, n_slabs, P):
+        pol = self.policy
+        A = pol.actor.n_actions
+        lib = ops._lib.load()
         # denominators of the masked means + the moments ValueNorm.update needs (cal_value_loss, r_mappo.py:65);
         # `moments_ready`: the minibatch is the whole buffer again, its sums were taken by the first epoch
         if not moments_ready:
@@ -101,8 +129,6 @@ class R_MAPPO():
         # at config 2 — so the chain stays on one stream.)
         if self._use_valuenorm:
             ops.valuenorm_update(vn_state, self._mb_moments, self.value_normalizer.beta)
-        n_slabs = ops.mlp_backward_slabs(B)
-        P = pol.n_flat
         slabs = self._buf("slabs", (n_slabs, P), zero=True)
         if not update_actor and not self._actor_slabs_clean:
             slabs[:, :pol.seg_bounds[1]].zero_()
@@ -152,18 +178,7 @@ class R_MAPPO():
             if update_actor:
                 ops.mlp_backward(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, dlogits, slabs, P, 0)
             ops.mlp_backward(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, dvalues, slabs, P, pol.seg_bounds[1])
-        if update_actor != self._actor_enabled:                  # torch >= 2: grad None => Adam skips the actor
-            pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
-            self._actor_enabled = update_actor
-        if self._dist is None:
-            # single process: reduction + clip + Adam in two launches
-            ops.reduce_clip_adam(slabs, n_slabs, P, pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds,
-                                 pol.opt_hyper, pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
-        else:
-            ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
-            self._dist.all_reduce_sum_(pol.flat_grad)          # C1: one flat fp32 all-reduce per minibatch
-            ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper,
-                          pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
+        return slabs
 
     _actor_slabs_clean = True
     _actor_enabled = True
@@ -235,13 +250,32 @@ class R_MAPPO():
         src, _ = self._buffer_sources(buffer, adv)
         self._acc.zero_()
         whole = self.num_mini_batch == 1 and not self._exact_order
+        dp_graph = self._dist is not None and self._use_graph and whole and self._fused and self._dist.world_is_gpu
+        key = (id(buffer), bool(update_actor))
         for epoch in range(self.ppo_epoch):
             if whole:
                 batches = [(None, S)]                      # whole buffer in place (see module docstring)
             else:
                 batches = [(rows, rows.numel()) for rows in buffer.feed_forward_rows(self.num_mini_batch)]
             for rows, B in batches:
-                self._update(src, rows, B, update_actor, moments_ready=whole and epoch > 0)
+                if dp_graph and epoch > 0:
+                    # data parallel: the collective stays outside; the kernels between two collectives are one hipGraph
+                    st = self._dp_graphs.get(key)
+                    if st == "warm":
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread stays legal
+                            self._update(src, rows, B, update_actor, moments_ready=True, part="kernels")
+                        self._dp_graphs[key] = st = g
+                    if st is None:
+                        self._update(src, rows, B, update_actor, moments_ready=True, part="kernels")
+                    else:
+                        st.replay()
+                    self._update(src, rows, B, update_actor, moments_ready=True, part="optim")
+                else:
+                    self._update(src, rows, B, update_actor, moments_ready=whole and epoch > 0)
+        if dp_graph and self._dp_graphs.get(key) is None:
+            self._dp_graphs[key] = "warm"                      # first train() ran eagerly: workspaces exist now
         if after_update:
             buffer.after_update()
 

@@ -28,6 +28,7 @@ class DataParallel:
             raise RuntimeError("DataParallel needs torch.distributed.init_process_group (nccl on GPUs, gloo in CPU tests)")
         self._dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.world_is_gpu = dist.get_backend(group) == "nccl"      # hipGraph segments only make sense on the GPU backend
 
     def all_reduce_sum_(self, tensor):
         """In-place SUM on the tensor's own device / current stream (no host sync for nccl)."""

@@ -19,8 +19,9 @@ class MPERunner(Runner):
         self._onehot = None
         self._rollout_graph = None          # None -> "warm" -> CUDAGraph
         self._fuse_step = bool(getattr(self.all_args, "fuse_rollout_step", True))
-        self._use_graph = bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False)) \
-            and config.get("dist_group") is None
+        # the rollout has no collective in it, so data-parallel ranks capture it too
+        self._use_graph = bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False))
+        self._dist_present = config.get("dist_group") is not None
 
     def run(self):
         self.warmup()
@@ -96,7 +97,8 @@ class MPERunner(Runner):
         if self._rollout_graph == "warm":
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            mode = dict(capture_error_mode="thread_local") if self._dist_present else {}     # RCCL's watchdog thread stays legal
+            with torch.cuda.graph(g, **mode):
                 self._rollout_body()
             self._rollout_graph = g
         self._rollout_graph.replay()
