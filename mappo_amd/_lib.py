@@ -7,7 +7,7 @@ import torch  # noqa: F401  — must come first: libmappo_hip.so has to bind to 
 #               launches from the second one fail with "no ROCm-capable device is detected")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmappo_hip.so")
+LIB_PATH = os.environ.get("MAPPO_HIP_LIB") or os.path.join(_HERE, "libmappo_hip.so")     # override: diagnostic builds only
 
 HIDDEN = 64
 MAX_ACTIONS = 32

@@ -136,15 +136,87 @@ __device__ __forceinline__ void commit_half(float *tX, float *tF, float *dummy, 
   }
 }
 
-// acc (32 features of this wave) += W[row0 + i][k] . (tin[k][s] * gamma[k] + beta[k]);  sWr = sW + row0
-__device__ __forceinline__ void layer_mfma1(f32x16 &acc, const float *sWr, const float *tin, const float *sG, const float *sBt,
-                                            int ksteps, int l31, int half) {
-#pragma unroll 8
-  for (int kk = 0; kk < ksteps; ++kk) {
-    const int k = 2 * kk + half;
-    const float b = tin[k * TP + l31] * sG[k] + sBt[k];
-    acc = mfma(sWr[k * WP + l31], b, acc);
+// acc += sum_{kk < n} A(kk) B(kk); FA / FB: LDS loads of the A / B operand of k-step kk.
+template <typename FA, typename FB>
+__device__ __forceinline__ void mfma_chain(f32x16 &acc, int n, FA fa, FB fb) {
+#ifdef EXP_MFMA_PIPE      // explicit 4-step operand double-buffering: measured SLOWER (register spills), kept for experiments
+  float a[4], b[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int kk = min(j, n - 1); a[j] = fa(kk); b[j] = fb(kk); }
+  for (int k0 = 0; k0 < n; k0 += 4) {
+    float an[4], bn[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int kk = min(k0 + 4 + j, n - 1); an[j] = fa(kk); bn[j] = fb(kk); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (k0 + j < n) acc = mfma(a[j], b[j], acc);        // wave-uniform bound
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = an[j]; b[j] = bn[j]; }
   }
+#else
+#pragma unroll 8
+  for (int kk = 0; kk < n; ++kk) acc = mfma(fa(kk), fb(kk), acc);
+#endif
+}
+
+// Folded weights (pair kernel): the LayerNorm affine of a layer's input is folded into the staged copy,
+//   W'[f][k] = W[f][k] * gamma[k],   b'[f] = b[f] + sum_k W[f][k] * beta[k]     (fold_affine below),
+// so the forward operand is the tile's xhat itself and  W'^T dz = d xhat  directly in the backward.
+// acc (32 features of this wave) += W'[row0 + i][k] . xhat[k][s];  sWr = sW + row0
+__device__ __forceinline__ void layer_mfma1(f32x16 &acc, const float *sWr, const float *tin, int ksteps, int l31, int half) {
+  mfma_chain(acc, ksteps, [&](int kk) { return sWr[(2 * kk + half) * WP + l31]; }, [&](int kk) { return tin[(2 * kk + half) * TP + l31]; });
+}
+
+// head output (accumulator layout) from the folded head weights
+__device__ __forceinline__ f32x16 head_forward1(const float *lds, const LdsMap &m, const float *tLast, int l31, int half) {
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float4 b = *reinterpret_cast<const float4 *>(lds + m.bh + 8 * q + 4 * half);
+    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+  }
+  const float *sW = lds + m.wh;
+  mfma_chain(acc, HID / 2, [&](int kk) { return sW[(2 * kk + half) * HP + l31]; }, [&](int kk) { return tLast[(2 * kk + half) * TP + l31]; });
+  return acc;
+}
+
+// In-place fold of the staged weights / biases (all waves of the workgroup; contains workgroup barriers).
+template <int LN, int HEAD>
+__device__ __forceinline__ void fold_affine(float *lds, const LdsMap &m, int D, int Dp, int wave, int n_waves, int lane) {
+  // (1) biases, one job per wave at a time (lane = output feature): b' = b + W beta
+  const int n_jobs = LN + 1 + (HEAD != 3 ? 1 : 0);
+  for (int job = wave; job < n_jobs; job += n_waves) {
+    if (job == 0) {
+      float acc = lds[m.b1 + lane];
+      for (int k = 0; k < D; ++k) acc += lds[m.w1 + k * WP + lane] * lds[m.fn_b + k];
+      lds[m.b1 + lane] = acc;
+    } else if (job <= LN) {
+      const int l = job - 1;
+      float acc = lds[m.b2[l] + lane];
+      const float *sW = lds + m.w2[l], *sB = lds + ln_b_of<LN>(m, l);
+#pragma unroll 8
+      for (int k = 0; k < HID; ++k) acc += sW[k * WP + lane] * sB[k];
+      lds[m.b2[l] + lane] = acc;
+    } else if (lane < 32) {
+      float acc = lds[m.bh + lane];
+      const float *sW = lds + m.wh, *sB = lds + ln_b_of<LN>(m, LN);
+#pragma unroll 8
+      for (int k = 0; k < HID; ++k) acc += sW[k * HP + lane] * sB[k];
+      lds[m.bh + lane] = acc;
+    }
+  }
+  __syncthreads();
+  // (2) weights: row k of every k-major matrix times gamma_in[k]
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  for (int e = tid; e < Dp * HID; e += nthr) { const int k = e >> 6, f = e & 63; lds[m.w1 + k * WP + f] *= lds[m.fn_w + k]; }
+#pragma unroll
+  for (int l = 0; l < LN; ++l)
+    for (int e = tid; e < HID * HID; e += nthr) { const int k = e >> 6, f = e & 63; lds[m.w2[l] + k * WP + f] *= lds[ln_w_of<LN>(m, l) + k]; }
+  if (HEAD != 3)
+    for (int e = tid; e < HID * 32; e += nthr) { const int k = e >> 5, a = e & 31; lds[m.wh + k * HP + a] *= lds[ln_w_of<LN>(m, LN) + k]; }
+  __syncthreads();
 }
 
 __device__ __forceinline__ void init_bias1(f32x16 &acc, const float *sB, int fh, int half) {
@@ -225,7 +297,7 @@ __device__ __forceinline__ void ln_act_backward1(f32x16 &dH, float *tile, float 
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const int r = 4 * q + c;
-      const float dxh = dH[r] * gq[c];
+      const float dxh = AFFINE ? dH[r] * gq[c] : dH[r];      // folded weights: W'^T dz is d xhat already
       dH[r] = dxh;
       m1 += dxh;
       m2 += dxh * xh[r];
@@ -251,12 +323,31 @@ __device__ __forceinline__ void ln_act_backward1(f32x16 &dH, float *tile, float 
   }
 }
 
-// raw products -> gradient partials for NTJ accumulator tiles of this wave (rows f = frow0 + ROWMAP(r, half) of the
-// consumer's weight, columns k = kcol0 + 32 tj + l31); see raw_to_grad.  dbv: db of row frow0 + l31 (any half).
+// Epilogue helpers.  The LDS copy of the weights is folded with gamma, so the RAW consumer weights come from global
+// memory (row-major [n_rows][ldw]); raw_w_load issues those loads for all tiles of a product up front — the caller
+// loads every product's weights before transforming the first one, so the epilogue pays one global latency, not five.
+// Tiles: rows f = frow0 + ROWMAP(r, half), columns k = kcol0 + 32 tj + l31.
+template <int NTJ>
+__device__ __forceinline__ void raw_w_load(float (&w)[NTJ][16], const float *__restrict__ gW, int ldw, int n_rows, int frow0, int K,
+                                           int kcol0, int n_tj, int l31, int half) {
+#pragma unroll
+  for (int tj = 0; tj < NTJ; ++tj) {
+    const int k = kcol0 + 32 * tj + l31;
+    const int kc = (k < K) ? k : 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = frow0 + ROWMAP(r, half);
+      const float t = gW[min(f, n_rows - 1) * ldw + kc];
+      w[tj][r] = (tj < n_tj && k < K && f < n_rows) ? t : 0.f;
+    }
+  }
+}
+
+// raw products -> gradient partials (see raw_to_grad in mlp_impl.h).  dbv: db of row frow0 + l31 (any half).
 // dg / dt (per tile): this wave's partial d gamma / d beta of column k, valid in every lane of that l31.
 template <int NTJ>
-__device__ __forceinline__ void raw_to_grad1(f32x16 (&g)[NTJ], float dbv, float *scr, const float *sW, int wstride, int frow0,
-                                             const float *sG, const float *sBt, int K, int kcol0, int n_tj, int lane, int l31, int half,
+__device__ __forceinline__ void raw_to_grad1(f32x16 (&g)[NTJ], const float (&w)[NTJ][16], float dbv, float *scr, const float *sG,
+                                             const float *sBt, int K, int kcol0, int n_tj, int lane, int l31, int half,
                                              float (&dg)[NTJ], float (&dt)[NTJ]) {
   if (lane < 32) scr[lane] = dbv;
   wave_lds_sync();
@@ -268,15 +359,14 @@ __device__ __forceinline__ void raw_to_grad1(f32x16 (&g)[NTJ], float dbv, float 
     const bool valid = k < K;
     const int kc = valid ? k : 0;
     const float gam = valid ? sG[kc] : 0.f, bet = valid ? sBt[kc] : 0.f;
-    float w[16], d[16];
+    float d[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { w[r] = sW[kc * wstride + frow0 + ROWMAP(r, half)]; d[r] = scr[ROWMAP(r, half)]; }
+    for (int r = 0; r < 16; ++r) d[r] = scr[ROWMAP(r, half)];
     float a0 = 0.f, a1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float wv = valid ? w[r] : 0.f;
-      a0 += wv * g[tj][r];
-      a1 += wv * d[r];
+      a0 += w[tj][r] * g[tj][r];
+      a1 += w[tj][r] * d[r];
       g[tj][r] = gam * g[tj][r] + bet * d[r];
     }
     dg[tj] = xhalf_sum(a0);
@@ -324,6 +414,9 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
   }
   stage_all_weights<LN>(lds, m, p.params, o, p.desc);
   __syncthreads();
+#ifndef EXP_NOFOLDPASS
+  fold_affine<LN, HEAD>(lds, m, D, Dp, wave, blockDim.x / WAVE, lane);
+#endif
   STAMP(0);   // staging
   float *tX = lds + m.tiles + pair * m.wave_stride;
   float *tH = tX + m.x_rows * TP;
@@ -368,13 +461,13 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
     {
       f32x16 acc;
       init_bias1(acc, lds + m.b1, fh, half);
-      layer_mfma1(acc, lds + m.w1 + row0, tX, lds + m.fn_w, lds + m.fn_b, Dp / 2, l31, half);
+      layer_mfma1(acc, lds + m.w1 + row0, tX, Dp / 2, l31, half);
       act_ln_to_tile1<RELU>(acc, tH, xch, ps, fh, lane, l31, half, st.mean[0], st.rstd[0], st.pos[0]);
       pair_sync(ps, lane);
 #pragma unroll
       for (int l = 0; l < LN; ++l) {
         init_bias1(acc, lds + m.b2[l], fh, half);
-        layer_mfma1(acc, lds + m.w2[l] + row0, tH + l * HID * TP, lds + ln_w_of<LN>(m, l), lds + ln_b_of<LN>(m, l), HID / 2, l31, half);
+        layer_mfma1(acc, lds + m.w2[l] + row0, tH + l * HID * TP, HID / 2, l31, half);
         act_ln_to_tile1<RELU>(acc, tH + (l + 1) * HID * TP, xch, ps, fh, lane, l31, half, st.mean[l + 1], st.rstd[l + 1], st.pos[l + 1]);
         pair_sync(ps, lane);
       }
@@ -391,7 +484,7 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
             tZ[s * TP + a] = (s < n_valid) ? p.dout[base * A + e] : 0.f;
           }
         } else {
-          const f32x16 z = head_forward(lds, m, tLast, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN), l31, half);
+          const f32x16 z = head_forward1(lds, m, tLast, l31, half);
           if (HEAD == 1) {
             head_to_tile(tZ, z, A, l31, half);
             wave_lds_sync();
@@ -465,12 +558,8 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dH[r] = 0.f;
       {
-        const float *sW = lds + m.w2[l - 1];
-#pragma unroll 4
-        for (int kk = 0; kk < HID / 2; ++kk) {
-          const int fo = 2 * kk + half;
-          dH = mfma(sW[(row0 + l31) * WP + fo], tCur[fo * TP + l31], dH);
-        }
+        const float *sW = lds + m.w2[l - 1] + (row0 + l31) * WP;
+        mfma_chain(dH, HID / 2, [&](int kk) { return sW[2 * kk + half]; }, [&](int kk) { return tCur[(2 * kk + half) * TP + l31]; });
       }
       STAMP(7);   // dH (hidden)
     }
@@ -516,6 +605,12 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
   auto put_rows = [&](int i, float val) { ve0[i] = (fh == 0) ? val : 0.f; ve1[i] = (fh == 1) ? val : 0.f; };   // entry row0 + l31
   {
     float *scr = lds + m.scratch + n_pairs * 128 + wave * 32;
+    // raw consumer weights of every product of this wave, all global loads in flight together
+    float wH[1][16], w2[LN > 0 ? LN : 1][2][16], w1[2][16];
+    if (HEAD != 3) raw_w_load<1>(wH, p.params + o.wh, HID, A, 0, HID, row0, 1, l31, half);
+#pragma unroll
+    for (int l = 0; l < LN; ++l) raw_w_load<2>(w2[l], p.params + o.w2[l], HID, HID, row0, HID, 0, 2, l31, half);
+    if (fnorm) raw_w_load<2>(w1, p.params + o.w1, D, HID, row0, D, 0, WIDE ? 2 : 1, l31, half);
     put_rows(0, gB[0]);
 #pragma unroll
     for (int l = 0; l < LN; ++l) put_rows(3 + 3 * l, gB[l + 1]);
@@ -528,8 +623,7 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
         __syncthreads();
         const float dbh = xch[l31];
         float dg[1], dt[1];
-        raw_to_grad1<1>(gWh, dbh, scr, lds + m.wh, HP, 0, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN), HID, row0, 1, lane, l31, half,
-                        dg, dt);
+        raw_to_grad1<1>(gWh, wH, dbh, scr, lds + ln_w_of<LN>(m, LN), lds + ln_b_of<LN>(m, LN), HID, row0, 1, lane, l31, half, dg, dt);
         put_rows(iw, dg[0]);
         put_rows(ib, dt[0]);
         ve0[V::BH] = (fh == 0) ? dbh : 0.f;
@@ -543,13 +637,12 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
     for (int l = LN - 1; l >= 0; --l) {
       const int iw = (l == 0) ? 1 : 4 + 3 * (l - 1), ib = iw + 1;
       float dg[2], dt[2];
-      raw_to_grad1<2>(gW2[l], gB[l + 1], scr, lds + m.w2[l], WP, row0, lds + ln_w_of<LN>(m, l), lds + ln_b_of<LN>(m, l), HID, 0, 2, lane,
-                      l31, half, dg, dt);
+      raw_to_grad1<2>(gW2[l], w2[l], gB[l + 1], scr, lds + ln_w_of<LN>(m, l), lds + ln_b_of<LN>(m, l), HID, 0, 2, lane, l31, half, dg, dt);
       ve0[iw] = dg[0]; ve1[iw] = dg[1]; ve0[ib] = dt[0]; ve1[ib] = dt[1];
     }
     if (fnorm) {
       float dg[2], dt[2];
-      raw_to_grad1<2>(gW1, gB[0], scr, lds + m.w1, WP, row0, lds + m.fn_w, lds + m.fn_b, D, 0, WIDE ? 2 : 1, lane, l31, half, dg, dt);
+      raw_to_grad1<2>(gW1, w1, gB[0], scr, lds + m.fn_w, lds + m.fn_b, D, 0, WIDE ? 2 : 1, lane, l31, half, dg, dt);
       ve0[V::FNW] = dg[0]; ve1[V::FNW] = dg[1]; ve0[V::FNB] = dt[0]; ve1[V::FNB] = dt[1];
     }
   }
