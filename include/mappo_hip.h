@@ -102,6 +102,11 @@ int mappo_minibatch_moments(const float *returns, const float *active_masks, con
                             mappo_stream_t stream);
 int mappo_valuenorm_update(float *vn_state /*[3] in/out*/, const double *mb_moments /*[4]*/,
                            double beta, mappo_stream_t stream);
+/* n successive ValueNorm.update calls with the SAME batch moments (ppo_epoch updates on whole-buffer minibatches) in
+ * one launch: states_out[e] (e = 0..n-1, 3 floats each) is the state after e+1 updates — what update e's value loss
+ * normalises with — and vn_state ends as states_out[n-1].  Same fp32 rounding sequence as n single calls. */
+int mappo_valuenorm_update_n(float *vn_state /*[3] in/out*/, const double *mb_moments /*[4]*/, double beta, int32_t n,
+                             float *states_out /*[n][3]*/, mappo_stream_t stream);
 
 /* ---- K5 (+K6): fused PPO loss forward+backward (r_mappo.py:52-89,124-141; act.py:154-160) ----------
  * One pass over the minibatch: availability masking, log-softmax, log-prob gather, entropy,
@@ -113,6 +118,10 @@ typedef struct {
   float clip_param, entropy_coef, value_loss_coef, huber_delta;
   int32_t use_huber_loss, use_clipped_value_loss, use_policy_active_masks, use_value_active_masks,
       use_valuenorm;
+  /* mappo_actor_update / mappo_critic_update: != 0 ADDS this launch's per-workgroup loss sums to `partials` instead of
+   * overwriting them.  With identical denominators in every update (whole-buffer minibatches) one mappo_update_stats
+   * call after the last epoch then yields the sum of the per-update statistics the trainer logs. */
+  int32_t accumulate_partials;
 } mappo_ppo_cfg;
 
 int64_t mappo_ppo_loss_workspace_bytes(int64_t B);

@@ -23,7 +23,7 @@ class PpoCfg(C.Structure):
     _fields_ = [("clip_param", C.c_float), ("entropy_coef", C.c_float), ("value_loss_coef", C.c_float),
                 ("huber_delta", C.c_float), ("use_huber_loss", C.c_int32), ("use_clipped_value_loss", C.c_int32),
                 ("use_policy_active_masks", C.c_int32), ("use_value_active_masks", C.c_int32),
-                ("use_valuenorm", C.c_int32)]
+                ("use_valuenorm", C.c_int32), ("accumulate_partials", C.c_int32)]
 
 
 _P, _I32, _I64, _F, _D, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64
@@ -41,6 +41,7 @@ SIGNATURES = {
     "mappo_moments_workspace_bytes": (_I64, [_I64]),
     "mappo_minibatch_moments": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "mappo_valuenorm_update": (C.c_int, [_P, _P, _D, _P]),
+    "mappo_valuenorm_update_n": (C.c_int, [_P, _P, _D, _I32, _P, _P]),
     "mappo_ppo_loss_workspace_bytes": (_I64, [_I64]),
     "mappo_ppo_loss_fwd_bwd": (C.c_int, [_P] * 16 + [C.POINTER(PpoCfg), _I64, _I32, _P]),
     "mappo_mlp_forward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P]),

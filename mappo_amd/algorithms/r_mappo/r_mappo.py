@@ -63,6 +63,8 @@ class R_MAPPO():
         self.value_normalizer = ValueNorm(1, device=self.device) if self._use_valuenorm else None
 
         self._cfg = ops.ppo_cfg(args)
+        self._cfg_acc = ops.ppo_cfg(args, accumulate_partials=True)
+        self._epochs = None                        # whole-buffer fused train(): per-epoch ValueNorm states + deferred statistics
         self._dist = dist_group                      # mappo_amd.distributed.DataParallel or None
         f64 = dict(dtype=torch.float64, device=self.device)
         self._mb_moments = torch.zeros(4, **f64)
@@ -119,15 +121,24 @@ class R_MAPPO():
         lib = ops._lib.load()
         # denominators of the masked means + the moments ValueNorm.update needs (cal_value_loss, r_mappo.py:65);
         # `moments_ready`: the minibatch is the whole buffer again, its sums were taken by the first epoch
+        ep = self._epochs
         if not moments_ready:
             ops.minibatch_moments(src["returns"], src["active"], rows, B, self._mb_moments,
                                   self._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
             if self._dist is not None:
                 self._dist.all_reduce_sum_(self._mb_moments)
+            if ep is not None and self._use_valuenorm:
+                # every epoch sees the same batch moments: all ppo_epoch ValueNorm updates in one launch
+                ops.valuenorm_update_n(vn_state, self._mb_moments, self.value_normalizer.beta, ep["n"], ep["states"])
         # (ValueNorm.update and the loss statistics are tiny kernels that nothing waits for immediately; forking them to a
         # side stream next to the update kernels measured SLOWER inside the captured hipGraph — train 1.96 ms vs 1.69 ms
         # at config 2 — so the chain stays on one stream.)
-        if self._use_valuenorm:
+        cfg = self._cfg
+        if ep is not None:
+            cfg = self._cfg_acc                               # loss sums accumulate over the epochs, one statistics launch at the end
+            if self._use_valuenorm:
+                vn_state = ep["states"][ep["e"]]              # state after this epoch's ValueNorm.update
+        elif self._use_valuenorm:
             ops.valuenorm_update(vn_state, self._mb_moments, self.value_normalizer.beta)
         slabs = self._buf("slabs", (n_slabs, P), zero=True)
         if not update_actor and not self._actor_slabs_clean:
@@ -150,19 +161,22 @@ class R_MAPPO():
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     ops.actor_update(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, src["avail"], src["actions"],
-                                     src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa, na)
+                                     src["old_logp"], src["adv"], src["active"], self._mb_moments, cfg, slabs, P, 0, pa, na)
                 ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
-                                  src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc, nc)
+                                  src["active"], vn_state, self._mb_moments, cfg, slabs, P, pol.seg_bounds[1], pc, nc)
                 cur.wait_stream(side)
                 n_pa, n_pc = na, nc
             else:
                 if update_actor:
                     ops.actor_update(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, src["avail"], src["actions"],
-                                     src["old_logp"], src["adv"], src["active"], self._mb_moments, self._cfg, slabs, P, 0, pa)
+                                     src["old_logp"], src["adv"], src["active"], self._mb_moments, cfg, slabs, P, 0, pa)
                 ops.critic_update(pol.critic.flat, pol.critic.desc, src["share_obs"], rows, B, src["v_old"], src["returns"],
-                                  src["active"], vn_state, self._mb_moments, self._cfg, slabs, P, pol.seg_bounds[1], pc)
+                                  src["active"], vn_state, self._mb_moments, cfg, slabs, P, pol.seg_bounds[1], pc)
                 n_pa = n_pc = n_slabs
-            ops.update_stats(pa if update_actor else None, n_pa, pc, n_pc, self._mb_moments, self._cfg, self._stats, self._acc)
+            if ep is None:
+                ops.update_stats(pa if update_actor else None, n_pa, pc, n_pc, self._mb_moments, self._cfg, self._stats, self._acc)
+            else:
+                ep["stats_args"] = (pa if update_actor else None, n_pa, pc, n_pc)
         else:
             # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
             logits = self._buf("logits", (B, A))
@@ -252,7 +266,16 @@ class R_MAPPO():
         whole = self.num_mini_batch == 1 and not self._exact_order
         dp_graph = self._dist is not None and self._use_graph and whole and self._fused and self._dist.world_is_gpu
         key = (id(buffer), bool(update_actor))
+        self._epochs = None
+        if whole and self._fused and self._dist is None and not self._concurrent_update and os.environ.get("MAPPO_EPOCH_BATCH", "1") != "0":
+            # every update sees the same minibatch (the whole buffer): ValueNorm's ppo_epoch updates are one launch, the
+            # loss sums accumulate in the kernels' partials and the statistics kernel runs once after the last epoch
+            self._epochs = dict(n=self.ppo_epoch, e=0, states=self._buf("vn_states", (self.ppo_epoch, 3)), stats_args=None)
+            self._buf("partials_a", (1024,), torch.float64, zero=True).zero_()
+            self._buf("partials_c", (1024,), torch.float64, zero=True).zero_()
         for epoch in range(self.ppo_epoch):
+            if self._epochs is not None:
+                self._epochs["e"] = epoch
             if whole:
                 batches = [(None, S)]                      # whole buffer in place (see module docstring)
             else:
@@ -274,6 +297,9 @@ class R_MAPPO():
                     self._update(src, rows, B, update_actor, moments_ready=True, part="optim")
                 else:
                     self._update(src, rows, B, update_actor, moments_ready=whole and epoch > 0)
+        if self._epochs is not None:
+            ops.update_stats(*self._epochs["stats_args"], self._mb_moments, self._cfg, self._stats, self._acc)
+            self._epochs = None
         if dp_graph and self._dp_graphs.get(key) is None:
             self._dp_graphs[key] = "warm"                      # first train() ran eagerly: workspaces exist now
         if after_update:

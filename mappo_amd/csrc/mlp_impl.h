@@ -1064,7 +1064,10 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
     block_sum<4>(lacc, red_smem);
     if (threadIdx.x == 0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) p.partials[(size_t)blockIdx.x * 4 + k] = lacc[k];
+      for (int k = 0; k < 4; ++k) {
+        double *q = p.partials + (size_t)blockIdx.x * 4 + k;
+        *q = p.cfg.accumulate_partials ? *q + lacc[k] : lacc[k];
+      }
     }
   }
 

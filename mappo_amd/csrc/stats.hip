@@ -155,3 +155,26 @@ extern "C" int mappo_valuenorm_update(float *vn_state, const double *mb_moments,
   MAPPO_CHECK_LAUNCH("valuenorm_update");
   return MAPPO_OK;
 }
+
+__global__ void valuenorm_update_n_kernel(float *vn_state, const double *mb_moments, float w, float omw, int n, float *states_out) {
+  const double B = mb_moments[3] > 0.0 ? mb_moments[3] : 1.0;
+  const float bm = (float)(mb_moments[0] / B);
+  const float bsq = (float)(mb_moments[1] / B);
+  float s0 = vn_state[0], s1 = vn_state[1], s2 = vn_state[2];
+  for (int e = 0; e < n; ++e) {
+    s0 = __fadd_rn(__fmul_rn(s0, w), __fmul_rn(bm, omw));
+    s1 = __fadd_rn(__fmul_rn(s1, w), __fmul_rn(bsq, omw));
+    s2 = __fadd_rn(__fmul_rn(s2, w), omw);
+    states_out[3 * e + 0] = s0; states_out[3 * e + 1] = s1; states_out[3 * e + 2] = s2;
+  }
+  vn_state[0] = s0; vn_state[1] = s1; vn_state[2] = s2;
+}
+
+extern "C" int mappo_valuenorm_update_n(float *vn_state, const double *mb_moments, double beta, int32_t n, float *states_out,
+                                        mappo_stream_t stream) {
+  MAPPO_REQUIRE(vn_state && mb_moments && states_out && n >= 1, "valuenorm_update_n: bad arguments");
+  hipLaunchKernelGGL(valuenorm_update_n_kernel, dim3(1), dim3(1), 0, as_stream(stream), vn_state, mb_moments, (float)beta,
+                     (float)(1.0 - beta), (int)n, states_out);
+  MAPPO_CHECK_LAUNCH("valuenorm_update_n");
+  return MAPPO_OK;
+}

@@ -100,12 +100,19 @@ def valuenorm_update(vn_state, mb_moments, beta=0.99999):
     _lib.check(rc, "mappo_valuenorm_update")
 
 
+def valuenorm_update_n(vn_state, mb_moments, beta, n, states_out):
+    """n ValueNorm.update calls with the same batch moments in one launch; states_out [n, 3]."""
+    rc = _lib.load().mappo_valuenorm_update_n(_ptr(vn_state), _ptr(mb_moments, torch.float64), float(beta), int(n), _ptr(states_out),
+                                              _stream())
+    _lib.check(rc, "mappo_valuenorm_update_n")
+
+
 # ---- K5 -------------------------------------------------------------------------------------------
-def ppo_cfg(args):
+def ppo_cfg(args, accumulate_partials=False):
     return PpoCfg(float(args.clip_param), float(args.entropy_coef), float(args.value_loss_coef), float(args.huber_delta),
                   int(bool(args.use_huber_loss)), int(bool(args.use_clipped_value_loss)),
                   int(bool(args.use_policy_active_masks)), int(bool(args.use_value_active_masks)),
-                  int(bool(args.use_valuenorm)))
+                  int(bool(args.use_valuenorm)), int(bool(accumulate_partials)))
 
 
 def ppo_loss_fwd_bwd(logits, values, rows, avail, actions, old_logp, adv, active, v_old, returns, vn_state, mb_moments,
