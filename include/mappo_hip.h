@@ -70,6 +70,10 @@ int mappo_insert_mpe(const float *obs, int64_t obs_stride_n, int64_t obs_stride_
                      int64_t done_stride_n, int64_t done_stride_m, float *obs_dst, float *share_dst, float *rew_dst,
                      float *mask_dst, int32_t N, int32_t M, int32_t D, int32_t centralized, mappo_stream_t stream);
 
+/* K1, after_update (shared_buffer.py:114-131): `count` (<= 16) independent fp32 device copies in one launch.
+ * dst / src / n_floats are HOST arrays of device pointers / lengths. */
+int mappo_copy_batch(int32_t count, float *const *dst, const float *const *src, const int64_t *n_floats, mappo_stream_t stream);
+
 /* ---- K2: compute_returns (shared_buffer.py:168-224), all four flag branches ------------------------
  * Segmented affine-map scan over T: one wavefront per (64 series x time segment), segment composites
  * combined through LDS.  Writes value_preds[T] <- next_value (GAE branches) or returns[T] <- next_value
@@ -156,7 +160,8 @@ int mappo_actor_act(const float *params, const mappo_net_desc *desc /*host*/, co
  * of the env output the rows are read from).  Rows may be strided views of the env's output: with M > 0 sample i is
  * (thread n, agent m) = (i / M, i % M) and starts at base[n*stride_n + m*stride_m]; M == 0: contiguous [B][in_dim].
  * obs_dst != NULL additionally performs mappo_insert_mpe(obs, rewards, dones -> obs_dst, share_dst, rew_dst, mask_dst)
- * (N = B / M threads) inside the same launch.  Networks with in_dim <= 64 that share layer_N and the activation. */
+ * (N = B / M threads) inside the same launch.  actions == logp == NULL skips the actor (bootstrap value of the last
+ * step: critic + insert).  Networks with in_dim <= 64 that share layer_N and the activation. */
 int mappo_rollout_step(const float *actor_params, const mappo_net_desc *actor_desc /*host*/, const float *critic_params,
                        const mappo_net_desc *critic_desc /*host*/, const float *obs, int64_t obs_stride_n,
                        int64_t obs_stride_m, const float *share_obs, int64_t share_stride_n, int64_t share_stride_m,

@@ -136,17 +136,19 @@ class R_MAPPOPolicy:
                 and a.use_relu == c.use_relu)
 
     @torch.no_grad()
-    def collect_step_fused(self, buffer, step, pending=None, centralized=True, use_available_actions=False, deterministic=False):
+    def collect_step_fused(self, buffer, step, pending=None, centralized=True, use_available_actions=False, deterministic=False,
+                           values_only=None):
         """get_actions on the rows of step `step` AND (pending = (obs, rewards, dones) of the env step before it) the
         insert of that env output into slot `step` — one kernel.  With `pending` the networks read the rows straight
         from the env's output (strided views are fine) while other workgroups of the same launch copy them into
         obs[step] / share_obs[step] / rewards[step-1] / masks[step]; without it they read the buffer slot.
         Returns the fp32 actions view [N, M, 1], or None when `pending` does not have the expected device layout
-        (the caller then falls back to insert + collect_into)."""
+        (the caller then falls back to insert + collect_into).  values_only = a [R] fp32 tensor: the bootstrap step
+        (step == episode_length) — only the critic runs, its values go to that tensor (base_runner.py:110-118)."""
         N, M = buffer.n_rollout_threads, buffer.num_agents
         R = N * M
         D = self.actor.desc.in_dim
-        avail = buffer.available_actions[step].view(R, -1) if use_available_actions else None
+        avail = buffer.available_actions[step].view(R, -1) if (use_available_actions and values_only is None) else None
         insert = None
         if pending is None:
             obs_src = (buffer.obs[step], 0, 0)
@@ -172,6 +174,10 @@ class R_MAPPOPolicy:
             insert = dict(obs_dst=buffer.obs[step], share_dst=buffer.share_obs[step], rewards=(rewards, rewards.stride(0), rewards.stride(1)),
                           dones=(dones, dones.stride(0), dones.stride(1)), rew_dst=buffer.rewards[step - 1], mask_dst=buffer.masks[step],
                           centralized=centralized)
+        if values_only is not None:
+            ops.rollout_step(self.actor.flat, self.actor.desc, self.critic.flat, self.critic.desc, obs_src, share_src, Mk, R, None,
+                             deterministic, self.actor._seed, step, None, None, None, values_only, insert)
+            return values_only
         ops.rollout_step(self.actor.flat, self.actor.desc, self.critic.flat, self.critic.desc, obs_src, share_src, Mk, R, avail,
                          deterministic, self.actor._seed, step, self.actor._counter_dev, buffer.actions[step].view(R),
                          buffer.action_log_probs[step].view(R), buffer.value_preds[step].view(R), insert)

@@ -70,7 +70,10 @@ class R_MAPPO():
         self._mb_moments = torch.zeros(4, **f64)
         self._adv_moments = torch.zeros(3, **f64)
         self._stats = torch.zeros(6, **f64)
-        self._acc = torch.zeros(6, **f64)            # value_loss, policy_loss, dist_entropy, ratio, actor_gn, critic_gn
+        # one allocation, one fill per train(): [statistics accumulators (6, padded to 8) | actor loss partials | critic loss partials]
+        self._zbuf = torch.zeros(8 + 2 * 1024, **f64)
+        self._acc = self._zbuf[:6]                   # value_loss, policy_loss, dist_entropy, ratio, actor_gn, critic_gn
+        self._pa, self._pc = self._zbuf[8:8 + 1024], self._zbuf[8 + 1024:]
         self._ws = {}
         self._training = False
 
@@ -145,8 +148,7 @@ class R_MAPPO():
             slabs[:, :pol.seg_bounds[1]].zero_()
         self._actor_slabs_clean = not update_actor
         if self._fused:
-            pa = self._buf("partials_a", (1024,), torch.float64, zero=True)
-            pc = self._buf("partials_c", (1024,), torch.float64, zero=True)
+            pa, pc = self._pa, self._pc
             # Each update kernel wants one workgroup per CU (its LDS footprint), so two full-size launches run one after
             # the other.  --concurrent_update instead splits the 256 CUs between the two networks and launches them on two
             # streams; on MI355X this measured SLOWER (train 3.08 ms vs 2.52 ms at config 2), so it is off by default.
@@ -262,7 +264,7 @@ class R_MAPPO():
         S = T * buffer.n_rollout_threads * buffer.num_agents
         adv = self.compute_advantages(buffer)
         src, _ = self._buffer_sources(buffer, adv)
-        self._acc.zero_()
+        self._zbuf.zero_()
         whole = self.num_mini_batch == 1 and not self._exact_order
         dp_graph = self._dist is not None and self._use_graph and whole and self._fused and self._dist.world_is_gpu
         key = (id(buffer), bool(update_actor))
@@ -271,8 +273,6 @@ class R_MAPPO():
             # every update sees the same minibatch (the whole buffer): ValueNorm's ppo_epoch updates are one launch, the
             # loss sums accumulate in the kernels' partials and the statistics kernel runs once after the last epoch
             self._epochs = dict(n=self.ppo_epoch, e=0, states=self._buf("vn_states", (self.ppo_epoch, 3)), stats_args=None)
-            self._buf("partials_a", (1024,), torch.float64, zero=True).zero_()
-            self._buf("partials_c", (1024,), torch.float64, zero=True).zero_()
         for epoch in range(self.ppo_epoch):
             if self._epochs is not None:
                 self._epochs["e"] = epoch

@@ -28,3 +28,47 @@ extern "C" int mappo_insert_mpe(const float *obs, int64_t obs_stride_n, int64_t 
   MAPPO_CHECK_LAUNCH("insert_mpe");
   return MAPPO_OK;
 }
+
+// K1 (after_update, shared_buffer.py:114-131): up to 16 independent device copies in ONE launch (the reference copies
+// slot T of eight arrays back to slot 0; as separate copies each is a launch of a few microseconds).
+#define COPY_MAX 16
+struct CopyBatch {
+  float *dst[COPY_MAX];
+  const float *src[COPY_MAX];
+  int64_t n[COPY_MAX];          // floats
+  int count;
+};
+__global__ __launch_bounds__(256) void copy_batch_kernel(CopyBatch c) {
+  for (int j = 0; j < c.count; ++j) {
+    const float *__restrict__ s = c.src[j];
+    float *__restrict__ d = c.dst[j];
+    const int64_t n = c.n[j];
+    if (((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+      const int64_t n4 = n >> 2;
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        reinterpret_cast<float4 *>(d)[i] = reinterpret_cast<const float4 *>(s)[i];
+      for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+    } else {
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) d[i] = s[i];
+    }
+  }
+}
+
+extern "C" int mappo_copy_batch(int32_t count, float *const *dst, const float *const *src, const int64_t *n_floats,
+                                mappo_stream_t stream) {
+  MAPPO_REQUIRE(count >= 1 && count <= COPY_MAX && dst && src && n_floats, "copy_batch: bad arguments (count=%d)", count);
+  CopyBatch c;
+  c.count = count;
+  int64_t total = 0;
+  for (int j = 0; j < count; ++j) {
+    MAPPO_REQUIRE(dst[j] && src[j] && n_floats[j] >= 0, "copy_batch: entry %d", j);
+    c.dst[j] = dst[j]; c.src[j] = src[j]; c.n[j] = n_floats[j];
+    total += n_floats[j];
+  }
+  int64_t nb = (total / 4 + 255) / 256;
+  if (nb < 1) nb = 1;
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(copy_batch_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), c);
+  MAPPO_CHECK_LAUNCH("copy_batch");
+  return MAPPO_OK;
+}

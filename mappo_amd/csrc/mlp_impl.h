@@ -1301,7 +1301,8 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
   MAPPO_REQUIRE(actor_desc->layer_N == critic_desc->layer_N && actor_desc->use_relu == critic_desc->use_relu,
                 "rollout_step: actor and critic must share layer_N and the activation");
   MAPPO_REQUIRE(critic_desc->out_dim == 1, "rollout_step: critic out_dim must be 1");
-  MAPPO_REQUIRE(actor_params && critic_params && obs && share_obs && actions && logp && values && B > 0 && M >= 0, "rollout_step: bad arguments");
+  MAPPO_REQUIRE(actor_params && critic_params && obs && share_obs && values && B > 0 && M >= 0 && (!actions == !logp),
+                "rollout_step: bad arguments");                  // actions == logp == NULL: critic (+ insert) only
   MAPPO_REQUIRE(M > 0 || !obs_dst, "rollout_step: the fused insert needs the (thread, agent) row layout (M > 0)");
   MAPPO_REQUIRE(!obs_dst || (share_dst && rewards && dones && rew_dst && mask_dst && B % M == 0), "rollout_step: incomplete insert arguments");
   MAPPO_CLEAR_STICKY();
@@ -1323,7 +1324,7 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "rollout_step: needs %zu B of LDS", lds_bytes);
   int64_t nb = (n_tiles + nw - 1) / nw;
   if (nb > NUM_CU / 2) nb = NUM_CU / 2;
-  s.nA = (int)nb; s.nC = (int)nb; s.nI = 0;
+  s.nA = actions ? (int)nb : 0; s.nC = (int)nb; s.nI = 0;
   if (obs_dst) {
     InsertArgs &i = s.ins;
     i.obs = obs; i.obs_sn = obs_stride_n; i.obs_sm = obs_stride_m; i.rew = rewards; i.rew_sn = rew_stride_n; i.rew_sm = rew_stride_m;

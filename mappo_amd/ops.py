@@ -55,6 +55,19 @@ def insert_mpe(obs, rewards, dones, obs_dst, share_dst, rew_dst, mask_dst, centr
     _lib.check(rc, "mappo_insert_mpe")
 
 
+def copy_batch(pairs):
+    """[(dst, src), ...] contiguous fp32 device tensors of equal numel per pair, copied in ONE launch (<= 16 pairs)."""
+    n = len(pairs)
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    src = (C.c_void_p * n)(*[s.data_ptr() for _, s in pairs])
+    cnt = (C.c_int64 * n)(*[d.numel() for d, _ in pairs])
+    for d, s_ in pairs:
+        assert d.is_cuda and s_.is_cuda and d.dtype == torch.float32 and s_.dtype == torch.float32 and d.is_contiguous() \
+            and s_.is_contiguous() and d.numel() == s_.numel()
+    rc = _lib.load().mappo_copy_batch(n, dst, src, cnt, _stream())
+    _lib.check(rc, "mappo_copy_batch")
+
+
 # ---- K2 -------------------------------------------------------------------------------------------
 def gae_scan(rewards, value_preds, next_value, masks, bad_masks, returns, vn_state, gamma, gae_lambda,
              use_gae=True, use_proper_time_limits=False):
@@ -162,8 +175,8 @@ def rollout_step(actor_params, actor_desc, critic_params, critic_desc, obs, shar
     rc = _lib.load().mappo_rollout_step(_ptr(actor_params), C.byref(actor_desc), _ptr(critic_params), C.byref(critic_desc),
                                         C.c_void_p(ot.data_ptr()), int(osn), int(osm), C.c_void_p(st.data_ptr()), int(ssn), int(ssm), int(M), int(B),
                                         _ptr(avail, allow_none=True), int(bool(deterministic)), int(seed) & (2 ** 64 - 1),
-                                        int(counter) & (2 ** 64 - 1), _ptr(counter_dev, torch.int64, allow_none=True), _ptr(actions),
-                                        _ptr(logp), _ptr(values), *ins, _stream())
+                                        int(counter) & (2 ** 64 - 1), _ptr(counter_dev, torch.int64, allow_none=True),
+                                        _ptr(actions, allow_none=True), _ptr(logp, allow_none=True), _ptr(values), *ins, _stream())
     _lib.check(rc, "mappo_rollout_step")
 
 

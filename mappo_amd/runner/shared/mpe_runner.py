@@ -19,6 +19,7 @@ class MPERunner(Runner):
         self._onehot = None
         self._rollout_graph = None          # None -> "warm" -> CUDAGraph
         self._fuse_step = bool(getattr(self.all_args, "fuse_rollout_step", True))
+        self._next_values = None
         # the rollout has no collective in it, so data-parallel ranks capture it too
         self._use_graph = bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False))
         self._dist_present = config.get("dist_group") is not None
@@ -80,7 +81,20 @@ class MPERunner(Runner):
             data = obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic
             self.insert(data)
         if fuse:
-            self.insert(pending + (None,) * 6)      # the last env output: plain insert kernel
+            # the last env output: its insert + the bootstrap value of compute() in one launch (critic workgroups + insert)
+            b = self.buffer
+            if self._next_values is None:
+                self._next_values = torch.empty(b.n_rollout_threads * b.num_agents, device=b.device)
+            nv = self.trainer.policy.collect_step_fused(b, self.episode_length, pending, self.use_centralized_V,
+                                                        values_only=self._next_values)
+            if nv is None:
+                self.insert(pending + (None,) * 6)
+                self.compute()
+            else:
+                b.step = 0
+                self.trainer.prep_rollout()
+                b.compute_returns(nv, self.trainer.value_normalizer)
+            return infos
         self.compute()
         return infos
 

@@ -143,10 +143,10 @@ class SharedReplayBuffer(object):
         self.step = (s + 1) % self.episode_length
 
     def after_update(self):
-        for arr in (self.share_obs, self.obs, self.rnn_states, self.rnn_states_critic, self.masks, self.bad_masks,
-                    self.active_masks, self.available_actions):
-            if arr is not None:
-                arr[0].copy_(arr[-1])
+        """shared_buffer.py:114-131: slot T of every carried array becomes slot 0 — one launch (mappo_copy_batch)."""
+        arrs = [a for a in (self.share_obs, self.obs, self.rnn_states, self.rnn_states_critic, self.masks, self.bad_masks,
+                            self.active_masks, self.available_actions) if a is not None]
+        ops.copy_batch([(a[0], a[-1]) for a in arrs])
 
     def chooseafter_update(self):
         for arr in (self.rnn_states, self.rnn_states_critic, self.masks, self.bad_masks):

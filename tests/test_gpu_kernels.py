@@ -653,3 +653,33 @@ def test_reduce_clip_adam_matches_slab_reduce_then_clip_adam(ops):
     np.testing.assert_array_equal(out[0][6], out[1][6])
     for a_, b_ in zip(out[0][1:6], out[1][1:6]):
         np.testing.assert_allclose(a_, b_, rtol=2e-6, atol=1e-7)
+
+
+def test_rollout_step_values_only_and_copy_batch(ops):
+    """actions == logp == NULL: critic + insert only (the bootstrap value of compute()); mappo_copy_batch == the copies."""
+    N, M, D = 40, 3, 18
+    R = N * M
+    g = torch.Generator(device="cuda").manual_seed(5)
+    blk = torch.randn(N, M * D + 1, device="cuda", generator=g)
+    obs = blk[:, :M * D].view(N, M, D)
+    rew = blk[:, M * D:].view(N, 1, 1).expand(N, M, 1)[..., 0]
+    dones = torch.rand(N, M, device="cuda", generator=g) > 0.5
+    da, dc = ops.net_desc(D, 5), ops.net_desc(M * D, 1)
+    pa = torch.randn(ops.net_param_count(da), device="cuda", generator=g) * 0.2
+    pc = torch.randn(ops.net_param_count(dc), device="cuda", generator=g) * 0.2
+    od, sd, rd, md = (torch.empty(s, device="cuda") for s in ((N, M, D), (N, M, M * D), (N, M, 1), (N, M, 1)))
+    ops.insert_mpe(obs, rew, dones, od, sd, rd, md, True)
+    v0 = torch.empty(R, 1, device="cuda")
+    ops.mlp_forward(pc, dc, sd.view(R, M * D), None, R, v0)
+    od1, sd1, rd1, md1 = (torch.full(s, float("nan"), device="cuda") for s in ((N, M, D), (N, M, M * D), (N, M, 1), (N, M, 1)))
+    v1 = torch.empty(R, device="cuda")
+    ins = dict(obs_dst=od1, share_dst=sd1, rewards=(rew, rew.stride(0), rew.stride(1)), dones=(dones, dones.stride(0), dones.stride(1)),
+               rew_dst=rd1, mask_dst=md1, centralized=True)
+    ops.rollout_step(pa, da, pc, dc, (obs, obs.stride(0), obs.stride(1)), (obs, obs.stride(0), 0), M, R, None, False, 0, 0, None, None, None, v1, ins)
+    for a_, b_ in ((od, od1), (sd, sd1), (rd, rd1), (md, md1), (v0.view(R), v1)):
+        np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+    srcs = [torch.randn(n, device="cuda", generator=g) for n in (7, 1024, 4099, 12)]
+    dsts = [torch.zeros_like(t) for t in srcs]
+    ops.copy_batch(list(zip(dsts, srcs)))
+    for a_, b_ in zip(srcs, dsts):
+        np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
