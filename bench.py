@@ -31,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+HBM_TRAFFIC_CRITIC_UPDATE_BYTES = 2 * 9008 * 1024 + 8124 * 1024     # measured offline, see roofline.traffic_note
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 
 
@@ -264,7 +265,11 @@ def main():
         flops = S * 6 * macs_critic                          # forward + dW + dX, 2 flop per MAC
         achieved = flops / (us * 1e-6) / 1e12
         roofline = dict(bound="mfma", kernel="mlp_update2_kernel<relu, layer_N=1, HEAD=critic, wide>", achieved=achieved,
-                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS, traffic=None,
+                        peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS,
+                        traffic=HBM_TRAFFIC_CRITIC_UPDATE_BYTES if (S == 76800 and args.num_mini_batch == 1) else None,
+                        traffic_note="HBM bytes per launch from rocprofv3 PMC passes of this workload (profiles/r01/g_update_kernels_hbm_pmc.csv): "
+                                     "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 18.4 MB + 8.3 MB; compulsory bytes: 16.6 MB rows + "
+                                     "0.9 MB loss inputs + 8.3 MB gradient slabs",
                         flops_per_launch=flops, launch_us=us,
                         note="algorithmic flops = 6 x forward MACs per sample (forward, dW, dX; SURVEY.md 8d); the kernel issues "
                              "fewer: the input layer needs no dX (feature-norm gradients come from the dW products)")
