@@ -93,8 +93,8 @@ __device__ __forceinline__ void load_state_rowmajor(f32x16 (&h)[2], const float 
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4 *>(src + row * HID + 32 * t + 8 * q + 4 * half);
+      float4 v = *reinterpret_cast<const float4 *>(src + (ok ? row : 0) * HID + 32 * t + 8 * q + 4 * half);
+      if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
       h[t][4 * q + 0] = v.x; h[t][4 * q + 1] = v.y; h[t][4 * q + 2] = v.z; h[t][4 * q + 3] = v.w;
     }
 }
@@ -112,7 +112,13 @@ __device__ __forceinline__ void load_fm(f32x16 (&v)[2], const float *__restrict_
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[t][r] = ok ? src[(int64_t)(32 * t + ROWMAP(r, half)) * ld + col] : 0.f;
+    for (int r = 0; r < 16; ++r) v[t][r] = src[(int64_t)(32 * t + ROWMAP(r, half)) * ld + (ok ? col : 0)];   // unconditional: all 32 in flight
+  if (!ok) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[t][r] = 0.f;
+  }
 }
 __device__ __forceinline__ void store_fm(float *__restrict__ dst, int64_t ld, int64_t col, const f32x16 (&v)[2], bool ok, int half) {
   if (!ok) return;
@@ -188,7 +194,11 @@ __device__ __forceinline__ void gru_cell(CellOut &c, const float *lds, const Gru
   // B operand of W_ih.x: lane (s, khalf) needs x[k = 2kk+khalf][s] = one coalesced 128-B segment per half -> registers
   float bx[HID / 2];
 #pragma unroll
-  for (int kk = 0; kk < HID / 2; ++kk) bx[kk] = ok ? xT[(int64_t)(2 * kk + half) * ldx + col] : 0.f;
+  for (int kk = 0; kk < HID / 2; ++kk) bx[kk] = xT[(int64_t)(2 * kk + half) * ldx + (ok ? col : 0)];      // unconditional: all in flight
+  if (!ok) {
+#pragma unroll
+    for (int kk = 0; kk < HID / 2; ++kk) bx[kk] = 0.f;
+  }
 #pragma unroll 4
   for (int kk = 0; kk < HID / 2; ++kk) {
     const int k = 2 * kk + half;
@@ -591,19 +601,34 @@ __global__ __launch_bounds__(256, 1) void gru_wgrad_kernel(GruWgArgs p) {
     const int t = tile / ct, c0 = (tile - t * ct) * TS;
     const int nv = min(TS, p.Nc - c0);
     const int64_t col0 = (int64_t)t * p.Nc + c0;
-    // stage: 96 gate rows (global row g_src) and 64 input rows, 32 columns each; two rows per wave instruction
-    for (int e = lane; e < 96 * TS; e += WAVE) {
-      const int gl = e >> 5, s = e & 31;
-      const int g = 96 * ghalf + gl;
-      const float *src = (mat == 1 && g >= 128) ? p.dghnT + (int64_t)(g - 128) * B : p.dgiT + (int64_t)g * B;
-      tA[gl * TP + s] = (s < nv) ? src[col0 + s] : 0.f;
-    }
-    const float *inb = (mat == 0) ? p.xT : p.scratch + (int64_t)SCR_HM * p.L * HID * p.Nc + (int64_t)t * HID * p.Nc;
-    const int64_t ldi = (mat == 0) ? B : p.Nc;
-    const int64_t ci = (mat == 0) ? col0 : c0;
-    for (int e = lane; e < HID * TS; e += WAVE) {
-      const int k = e >> 5, s = e & 31;
-      tB[k * TP + s] = (s < nv) ? inb[(int64_t)k * ldi + ci + s] : 0.f;
+    // stage: 96 gate rows and 64 input rows, 32 columns each; a wave instruction covers two rows (2 x 128 B).  Loads are
+    // unconditional (clamped column) and issued 16 at a time before their LDS stores: a predicated load would be waited
+    // for on its own, which made this kernel latency-bound (80 serial global loads per tile).
+    {
+      const int s = lane & 31, sc = min(s, nv - 1), r2 = lane >> 5;
+#pragma unroll
+      for (int b0 = 0; b0 < 48; b0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int gl = 2 * (b0 + j) + r2, g = 96 * ghalf + gl;
+          const float *src = (mat == 1 && g >= 128) ? p.dghnT + (int64_t)(g - 128) * B : p.dgiT + (int64_t)g * B;
+          v[j] = src[col0 + sc];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tA[(2 * (b0 + j) + r2) * TP + s] = (s < nv) ? v[j] : 0.f;
+      }
+      const float *inb = (mat == 0) ? p.xT : p.scratch + (int64_t)SCR_HM * p.L * HID * p.Nc + (int64_t)t * HID * p.Nc;
+      const int64_t ldi = (mat == 0) ? B : p.Nc;
+      const int64_t ci = (mat == 0) ? col0 : c0;
+#pragma unroll
+      for (int b0 = 0; b0 < 32; b0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = inb[(int64_t)(2 * (b0 + j) + r2) * ldi + ci + sc];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) tB[(2 * (b0 + j) + r2) * TP + s] = (s < nv) ? v[j] : 0.f;
+      }
     }
     wave_lds_sync();
 #pragma unroll 2

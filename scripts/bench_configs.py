@@ -2,7 +2,7 @@
 usage: python scripts/bench_configs.py [c1 c3 c4 c5 ...]"""
 import json, sys, time
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from mappo_amd.config import get_config
 from mappo_amd.envs.synthetic import SyntheticMPEEnv, SyntheticSMACEnv
 from mappo_amd.runner.shared.mpe_runner import MPERunner
