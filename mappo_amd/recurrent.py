@@ -22,8 +22,9 @@ class _Scratch:
     def __init__(self):
         self._c = {}
 
-    def get(self, device, L, Nc, training):
-        key = (L, Nc, training)
+    def get(self, device, L, Nc, training, tag=0):
+        """`tag` separates the networks: the actor's and the critic's passes run on two streams at the same time."""
+        key = (L, Nc, training, tag)
         s = self._c.get(key)
         if s is None:
             B = L * Nc
@@ -51,7 +52,7 @@ def actor_step(actor, obs, rnn_states, masks, avail, deterministic, actions_f, l
     L, Nc = _seq_shape(B, rnn_states)
     if L != 1:
         raise NotImplementedError("R_Actor.forward samples one step per row (the reference does the same: rnn.py:25-29)")
-    s = _scratch.get(actor.device_, 1, Nc, False)
+    s = _scratch.get(actor.device_, 1, Nc, False, "actor")
     ops.mlp_features(actor.flat, actor.desc, obs, None, B, s["featT"])
     h_next = torch.empty(Nc, actor._recurrent_N, H, dtype=torch.float32, device=actor.device_)
     if counter is None:
@@ -67,7 +68,7 @@ def actor_sequence_logits(actor, obs, rnn_states, masks):
     """Pre-mask logits for every row of a (L*Nc)-row time-major batch (evaluate_actions, r_actor_critic.py:72-107)."""
     B = obs.shape[0]
     L, Nc = _seq_shape(B, rnn_states)
-    s = _scratch.get(actor.device_, L, Nc, False)
+    s = _scratch.get(actor.device_, L, Nc, False, "actor")
     ops.mlp_features(actor.flat, actor.desc, obs, None, B, s["featT"])
     logits = torch.empty(B, actor.n_actions, dtype=torch.float32, device=actor.device_)
     ops.gru_forward(actor.flat, actor.desc, s["featT"], rnn_states.reshape(Nc, H), None, masks.reshape(B), None, L, Nc,
@@ -79,7 +80,7 @@ def critic_forward(critic, cent_obs, rnn_states, masks, values):
     """R_Critic.forward (r_actor_critic.py:146-165): single step (rows == states) or L-step sequences."""
     B = cent_obs.shape[0]
     L, Nc = _seq_shape(B, rnn_states)
-    s = _scratch.get(critic.device_, L, Nc, False)
+    s = _scratch.get(critic.device_, L, Nc, False, "critic")
     ops.mlp_features(critic.flat, critic.desc, cent_obs, None, B, s["featT"])
     h_next = torch.empty(Nc, critic._recurrent_N, H, dtype=torch.float32, device=critic.device_)
     ops.gru_forward(critic.flat, critic.desc, s["featT"], rnn_states.reshape(Nc, H), None, masks.reshape(B), None, L, Nc,
@@ -110,12 +111,13 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
     tr._actor_slabs_clean = not update_actor
     pa = tr._buf("partials_a", (1024,), torch.float64, zero=True)
     pc = tr._buf("partials_c", (1024,), torch.float64, zero=True)
-    s = _scratch.get(dev, L, Nc, True)
     nets = []
     if update_actor:
-        nets.append((pol.actor, src["obs"], src["h0_a"], 1, pa, 0))
-    nets.append((pol.critic, src["share_obs"], src["h0_c"], 2, pc, pol.seg_bounds[1]))
-    for net, x, h0, head, part, col0 in nets:
+        nets.append((pol.actor, src["obs"], src["h0_a"], 1, pa, 0, "actor"))
+    nets.append((pol.critic, src["share_obs"], src["h0_c"], 2, pc, pol.seg_bounds[1], "critic"))
+
+    def one_net(net, x, h0, head, part, col0, tag):
+        s = _scratch.get(dev, L, Nc, True, tag)
         ops.mlp_features(net.flat, net.desc, x, rows, B, s["featT"])
         ops.gru_forward(net.flat, net.desc, s["featT"], h0, h0_rows, src["masks"], rows, L, Nc, scratch=s["gates"], head_mode=0)
         ops.gru_backward(net.flat, net.desc, s["gates"], src["masks"], rows, L, Nc, head,
@@ -125,6 +127,21 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
                          vn_state if head == 2 else None, tr._mb_moments, tr._cfg, s["dxT"], s["dgiT"], s["dghnT"], slabs, P, col0, part)
         ops.gru_wgrad(net.desc, s["featT"], s["gates"], s["dgiT"], s["dghnT"], L, Nc, slabs, P, col0)
         ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
+
+    # The sequential GRU kernels occupy one wave per 32 sequences (240 of the chip's 1024 SIMDs at BASELINE config 2), so
+    # the two networks' chains run side by side on two streams; they write disjoint slab columns and disjoint partials.
+    if len(nets) == 2:
+        cur = torch.cuda.current_stream()
+        if tr._side_stream is None:
+            tr._side_stream = torch.cuda.Stream(device=dev)
+        side = tr._side_stream
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            one_net(*nets[0])
+        one_net(*nets[1])
+        cur.wait_stream(side)
+    else:
+        one_net(*nets[0])
     ops.update_stats(pa if update_actor else None, n_bwd, pc, n_bwd, tr._mb_moments, tr._cfg, tr._stats, tr._acc)
     ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
     if tr._dist is not None:
