@@ -286,10 +286,18 @@ class R_MAPPO():
                     st = self._dp_graphs.get(key)
                     if st == "warm":
                         torch.cuda.synchronize()
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread stays legal
-                            self._update(src, rows, B, update_actor, moments_ready=True, part="kernels")
-                        self._dp_graphs[key] = st = g
+                        try:
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread stays legal
+                                self._update(src, rows, B, update_actor, moments_ready=True, part="kernels")
+                            self._dp_graphs[key] = st = g
+                        except Exception as e:                      # never let a failed capture take a multi-GPU run down
+                            import warnings
+                            warnings.warn(f"hipGraph capture of the data-parallel update segment failed ({e}); launching eagerly")
+                            torch.cuda.synchronize()
+                            self._dp_graphs[key] = st = "off"
+                    if st == "off":
+                        st = None
                     if st is None:
                         self._update(src, rows, B, update_actor, moments_ready=True, part="kernels")
                     else:

@@ -196,10 +196,11 @@ _wide_ws_cache = {}
 
 
 def wide_workspace(desc, B, device):
-    """Scratch of the wide-input path (None for in_dim <= 64), cached per (B, device)."""
+    """Scratch of the wide-input path (None for in_dim <= 64), cached per (B, device, stream): two networks' backward
+    passes may run on two streams at the same time (recurrent training) and must not share it."""
     if desc.in_dim <= 64:
         return None
-    key = (int(B), str(device))
+    key = (int(B), str(device), int(torch.cuda.current_stream().cuda_stream))
     ws = _wide_ws_cache.get(key)
     if ws is None:
         ws = torch.empty(int(_lib.load().mappo_wide_workspace_floats(int(B))), dtype=torch.float32, device=device)

@@ -110,11 +110,20 @@ class MPERunner(Runner):
             return infos
         if self._rollout_graph == "warm":
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
             mode = dict(capture_error_mode="thread_local") if self._dist_present else {}     # RCCL's watchdog thread stays legal
-            with torch.cuda.graph(g, **mode):
-                self._rollout_body()
-            self._rollout_graph = g
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **mode):
+                    self._rollout_body()
+                self._rollout_graph = g
+            except Exception as e:
+                if not self._dist_present:
+                    raise
+                import warnings                              # never let a failed capture take a multi-GPU run down
+                warnings.warn(f"hipGraph capture of the rollout failed ({e}); launching eagerly")
+                torch.cuda.synchronize()
+                self._use_graph = False
+                return self._rollout_body()
         self._rollout_graph.replay()
         return None
 
