@@ -136,28 +136,25 @@ __device__ __forceinline__ void commit_half(float *tX, float *tF, float *dummy, 
   }
 }
 
-// acc += sum_{kk < n} A(kk) B(kk); FA / FB: LDS loads of the A / B operand of k-step kk.
-template <typename FA, typename FB>
-__device__ __forceinline__ void mfma_chain(f32x16 &acc, int n, FA fa, FB fb) {
-#ifdef EXP_MFMA_PIPE      // explicit 4-step operand double-buffering: measured SLOWER (register spills), kept for experiments
-  float a[4], b[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { const int kk = min(j, n - 1); a[j] = fa(kk); b[j] = fb(kk); }
+// Pointer form: A(kk) = pa[kk * sa], B(kk) = pb[kk * sb] (LDS).  The operands run two k-steps ahead
+// of their MFMA; the window may read up to 5 steps past n — rows that exist in LDS (the next matrix / tile) and are
+// never fed to an MFMA.
+__device__ __forceinline__ void mfma_chain_p(f32x16 &acc, int n, const float *pa, int sa, const float *pb, int sb) {
+#if !defined(EXP_MFMA_NOPIPE)
+  float a[6], b[6];
+  a[0] = pa[0]; b[0] = pb[0]; a[1] = pa[sa]; b[1] = pb[sb];
   for (int k0 = 0; k0 < n; k0 += 4) {
-    float an[4], bn[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const int kk = min(k0 + 4 + j, n - 1); an[j] = fa(kk); bn[j] = fb(kk); }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (k0 + j < n) acc = mfma(a[j], b[j], acc);        // wave-uniform bound
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { a[j] = an[j]; b[j] = bn[j]; }
+    for (int j = 0; j < 4; ++j) {
+      a[j + 2] = pa[(j + 2) * sa]; b[j + 2] = pb[(j + 2) * sb];
+      if (k0 + j < n) acc = mfma(a[j], b[j], acc);
+    }
+    a[0] = a[4]; b[0] = b[4]; a[1] = a[5]; b[1] = b[5];
+    pa += 4 * sa; pb += 4 * sb;
   }
 #else
 #pragma unroll 8
-  for (int kk = 0; kk < n; ++kk) acc = mfma(fa(kk), fb(kk), acc);
+  for (int kk = 0; kk < n; ++kk) acc = mfma(pa[kk * sa], pb[kk * sb], acc);
 #endif
 }
 
@@ -166,7 +163,7 @@ __device__ __forceinline__ void mfma_chain(f32x16 &acc, int n, FA fa, FB fb) {
 // so the forward operand is the tile's xhat itself and  W'^T dz = d xhat  directly in the backward.
 // acc (32 features of this wave) += W'[row0 + i][k] . xhat[k][s];  sWr = sW + row0
 __device__ __forceinline__ void layer_mfma1(f32x16 &acc, const float *sWr, const float *tin, int ksteps, int l31, int half) {
-  mfma_chain(acc, ksteps, [&](int kk) { return sWr[(2 * kk + half) * WP + l31]; }, [&](int kk) { return tin[(2 * kk + half) * TP + l31]; });
+  mfma_chain_p(acc, ksteps, sWr + half * WP + l31, 2 * WP, tin + half * TP + l31, 2 * TP);
 }
 
 // head output (accumulator layout) from the folded head weights
@@ -178,7 +175,7 @@ __device__ __forceinline__ f32x16 head_forward1(const float *lds, const LdsMap &
     acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
   }
   const float *sW = lds + m.wh;
-  mfma_chain(acc, HID / 2, [&](int kk) { return sW[(2 * kk + half) * HP + l31]; }, [&](int kk) { return tLast[(2 * kk + half) * TP + l31]; });
+  mfma_chain_p(acc, HID / 2, sW + half * HP + l31, 2 * HP, tLast + half * TP + l31, 2 * TP);
   return acc;
 }
 
@@ -559,7 +556,7 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
       for (int r = 0; r < 16; ++r) dH[r] = 0.f;
       {
         const float *sW = lds + m.w2[l - 1] + (row0 + l31) * WP;
-        mfma_chain(dH, HID / 2, [&](int kk) { return sW[2 * kk + half]; }, [&](int kk) { return tCur[(2 * kk + half) * TP + l31]; });
+        mfma_chain_p(dH, HID / 2, sW + half, 2, tCur + half * TP + l31, 2 * TP);
       }
       STAMP(7);   // dH (hidden)
     }
