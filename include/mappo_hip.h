@@ -206,6 +206,17 @@ int mappo_critic_update(const float *params, const mappo_net_desc *desc /*host*/
                         const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
                         int64_t slab_stride, int64_t slab_col0, double *partials, float *wide_ws /*or NULL*/,
                         int32_t n_blocks, mappo_stream_t stream);
+/* mappo_actor_update + mappo_critic_update in ONE launch (in_dim <= 64, shared layer_N / activation): each network runs
+ * on half the CUs and writes mappo_dual_update_slabs(B) slab rows of its own columns and as many partial rows.  Alone,
+ * each kernel leaves the chip with a ragged last round of tiles; side by side they share one. */
+int32_t mappo_dual_update_slabs(int64_t B);
+int mappo_actor_critic_update(const float *actor_params, const mappo_net_desc *actor_desc /*host*/, const float *obs,
+                              const float *critic_params, const mappo_net_desc *critic_desc /*host*/, const float *share_obs,
+                              const int32_t *rows, int64_t B, const float *avail, const float *actions, const float *old_logp,
+                              const float *adv, const float *active, const float *v_old, const float *returns,
+                              const float *vn_state, const double *mb_moments, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
+                              int64_t slab_stride, int64_t actor_col0, int64_t critic_col0, double *actor_partials,
+                              double *critic_partials, mappo_stream_t stream);
 int mappo_update_stats(const double *actor_partials, int32_t n_actor /*workgroups that wrote them*/,
                        const double *critic_partials, int32_t n_critic, const double *mb_moments,
                        const mappo_ppo_cfg *cfg /*host*/, double *stats /*[6]*/,

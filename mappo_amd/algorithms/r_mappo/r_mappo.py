@@ -64,6 +64,7 @@ class R_MAPPO():
 
         self._cfg = ops.ppo_cfg(args)
         self._cfg_acc = ops.ppo_cfg(args, accumulate_partials=True)
+        self._dual_update = bool(getattr(args, "dual_update", True)) and os.environ.get("MAPPO_DUAL_UPDATE", "1") != "0"
         self._epochs = None                        # whole-buffer fused train(): per-epoch ValueNorm states + deferred statistics
         self._dist = dist_group                      # mappo_amd.distributed.DataParallel or None
         f64 = dict(dtype=torch.float64, device=self.device)
@@ -100,7 +101,9 @@ class R_MAPPO():
         n_slabs = ops.mlp_backward_slabs(B)
         P = pol.n_flat
         if part != "optim":
+            self._slab_rows = n_slabs
             slabs = self._update_kernels(src, rows, B, update_actor, moments_ready, vn_state, n_slabs, P)
+            n_slabs = self._slab_rows                      # the dual launch writes fewer slab rows per network
         else:
             slabs = self._buf("slabs", (n_slabs, P))
         if update_actor != self._actor_enabled and part != "kernels":      # torch >= 2: grad None => Adam skips the actor
@@ -168,6 +171,13 @@ class R_MAPPO():
                                   src["active"], vn_state, self._mb_moments, cfg, slabs, P, pol.seg_bounds[1], pc, nc)
                 cur.wait_stream(side)
                 n_pa, n_pc = na, nc
+            elif update_actor and self._dual_update and pol.can_fuse_step():
+                # both networks in ONE launch, half the CUs each (mappo_actor_critic_update): one ragged tail instead of two
+                ops.actor_critic_update(pol.actor.flat, pol.actor.desc, src["obs"], pol.critic.flat, pol.critic.desc, src["share_obs"],
+                                        rows, B, src["avail"], src["actions"], src["old_logp"], src["adv"], src["active"], src["v_old"],
+                                        src["returns"], vn_state, self._mb_moments, cfg, slabs, P, 0, pol.seg_bounds[1], pa, pc)
+                n_pa = n_pc = ops.dual_update_slabs(B)
+                self._slab_rows = n_pa
             else:
                 if update_actor:
                     ops.actor_update(pol.actor.flat, pol.actor.desc, src["obs"], rows, B, src["avail"], src["actions"],

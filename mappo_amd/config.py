@@ -92,6 +92,9 @@ def get_config():
     p.add_argument("--fuse_rollout_step", **off,
                    help="by default an MLP policy's rollout step (insert of the previous env output + get_actions + get_values) "
                         "is ONE kernel launch (mappo_rollout_step); pass the flag to use the separate insert / actor / critic launches")
+    p.add_argument("--dual_update", **off,
+                   help="by default the actor's and the critic's fused update run in ONE launch, half the CUs each "
+                        "(mappo_actor_critic_update); pass the flag to launch them one after the other")
     p.add_argument("--concurrent_update", **on,
                    help="launch the actor and critic update kernels side by side on a split grid (two streams); measured "
                         "slower than back-to-back full-size launches on MI355X, kept for experiments")

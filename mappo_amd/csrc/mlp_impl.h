@@ -1189,6 +1189,9 @@ int upd_inst(int xw, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, co
 // pair kernel (mlp_upd2.h), in_dim <= 64: translation units mlp_upd2_r{0,1}_l{0,1,2}.hip
 template <bool R, int L, int HEAD>
 int upd2_inst(bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who);
+// actor + critic in one launch (mlp_update2_dual_kernel): translation units mlp_upd2d_r{0,1}_l{0,1,2}.hip
+template <bool R, int L>
+int upd2d_inst(bool wide_a, bool wide_c, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const DualArgs &d);
 
 #ifdef MLP_TU_UPD
 template <bool R, int L, int HEAD, int W>
@@ -1235,6 +1238,27 @@ template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 0>(bool, dim3, dim3, size_t, hi
 template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 1>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
 template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 2>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
 template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 3>(bool, dim3, dim3, size_t, hipStream_t, const UpdArgs &, const char *);
+#endif
+
+#ifdef MLP_TU_UPD2D
+template <bool R, int L, bool WA, bool WC>
+static int upd2d_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const DualArgs &d) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update2_dual_kernel<R, L, WA, WC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)LDS_DYN_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("actor_critic_update: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update2_dual_kernel<R, L, WA, WC>), grid, block, lds_bytes, st, d);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+int upd2d_inst(bool wa, bool wc, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const DualArgs &d) {
+  if (wa) return wc ? upd2d_launch<R, L, true, true>(grid, block, lds_bytes, st, d) : upd2d_launch<R, L, true, false>(grid, block, lds_bytes, st, d);
+  return wc ? upd2d_launch<R, L, false, true>(grid, block, lds_bytes, st, d) : upd2d_launch<R, L, false, false>(grid, block, lds_bytes, st, d);
+}
+template int upd2d_inst<MLP_UPD_RELU, MLP_UPD_LN>(bool, bool, dim3, dim3, size_t, hipStream_t, const DualArgs &);
 #endif
 
 #if defined(MLP_TU_MAIN) || defined(MLP_TU_STEP)
@@ -1534,6 +1558,77 @@ extern "C" int mappo_critic_update(const float *params, const mappo_net_desc *de
   a.desc = *desc; a.B = B; a.v_old = v_old; a.returns = returns; a.active = active; a.vn_state = vn_state;
   a.mb_moments = mb_moments; a.partials = partials; a.cfg = *cfg; a.wide_ws = wide_ws; a.n_blocks = n_blocks;
   return launch_update<2>(a, as_stream(stream), "critic_update");
+}
+
+// ---- actor + critic update in one launch --------------------------------------------------------------------------
+static int prep_pair(UpdArgs &a, int np, const char *who) {
+  a.off = net_offsets(a.desc);
+  MAPPO_REQUIRE(a.slab_col0 >= 0 && a.slab_col0 + a.off.total <= a.slab_stride, "%s: slab column range", who);
+  a.map = lds_map(a.desc, np);
+  a.p_red = a.off.total;
+  a.red_base = 0;
+  const int LN = a.desc.layer_N;
+  const int tile_area = np * a.map.wave_stride, vec_floats = 2 * np * (3 * (LN + 1) + 3) * 64;
+  a.n_regions = (np > 1 && 2 * a.p_red + vec_floats <= tile_area) ? 2 : 1;
+  MAPPO_REQUIRE(a.n_regions * a.p_red + vec_floats <= tile_area, "%s: reduction buffer too small", who);
+  return MAPPO_OK;
+}
+
+extern "C" int32_t mappo_dual_update_slabs(int64_t B) {
+  // slab rows (= workgroups) EACH network writes in mappo_actor_critic_update: half the CUs each
+  int64_t n_tiles = (B + TS - 1) / TS;
+  return (int32_t)(n_tiles < NUM_CU / 2 ? n_tiles : NUM_CU / 2);
+}
+
+extern "C" int mappo_actor_critic_update(const float *actor_params, const mappo_net_desc *actor_desc, const float *obs,
+                                         const float *critic_params, const mappo_net_desc *critic_desc, const float *share_obs,
+                                         const int32_t *rows, int64_t B, const float *avail, const float *actions,
+                                         const float *old_logp, const float *adv, const float *active, const float *v_old,
+                                         const float *returns, const float *vn_state, const double *mb_moments,
+                                         const mappo_ppo_cfg *cfg, float *slabs, int64_t slab_stride, int64_t actor_col0,
+                                         int64_t critic_col0, double *actor_partials, double *critic_partials,
+                                         mappo_stream_t stream) {
+  if (int rc = check_desc(actor_desc, "actor_critic_update")) return rc;
+  if (int rc = check_desc(critic_desc, "actor_critic_update")) return rc;
+  MAPPO_REQUIRE(actor_desc->in_dim <= MAXD && critic_desc->in_dim <= MAXD, "actor_critic_update: in_dim > %d takes the separate launches", MAXD);
+  MAPPO_REQUIRE(actor_desc->layer_N == critic_desc->layer_N && actor_desc->use_relu == critic_desc->use_relu,
+                "actor_critic_update: actor and critic must share layer_N and the activation");
+  MAPPO_REQUIRE(critic_desc->out_dim == 1, "actor_critic_update: critic out_dim must be 1");
+  MAPPO_REQUIRE(actor_params && critic_params && obs && share_obs && actions && old_logp && adv && active && v_old && returns && mb_moments &&
+                    cfg && slabs && actor_partials && critic_partials && B > 0, "actor_critic_update: bad arguments");
+  MAPPO_REQUIRE(!cfg->use_valuenorm || vn_state, "actor_critic_update: use_valuenorm needs vn_state");
+  MAPPO_CLEAR_STICKY();
+  DualArgs d = {};
+  UpdArgs &a = d.a, &c = d.c;
+  a.params = actor_params; a.x = obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = actor_col0;
+  a.desc = *actor_desc; a.B = B; a.avail = avail; a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.active = active;
+  a.mb_moments = mb_moments; a.partials = actor_partials; a.cfg = *cfg;
+  c.params = critic_params; c.x = share_obs; c.rows = rows; c.slabs = slabs; c.slab_stride = slab_stride; c.slab_col0 = critic_col0;
+  c.desc = *critic_desc; c.B = B; c.v_old = v_old; c.returns = returns; c.active = active; c.vn_state = vn_state;
+  c.mb_moments = mb_moments; c.partials = critic_partials; c.cfg = *cfg;
+  int np = fit_waves(a.desc, 4);
+  const int npc = fit_waves(c.desc, 4);
+  np = np < npc ? np : npc;
+  if (int rc = prep_pair(a, np, "actor_critic_update")) return rc;
+  if (int rc = prep_pair(c, np, "actor_critic_update")) return rc;
+  const int ta = a.map.total, tc = c.map.total;
+  const size_t lds_bytes = (size_t)(ta > tc ? ta : tc) * sizeof(float);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "actor_critic_update: needs %zu B of LDS", lds_bytes);
+  d.nA = d.nC = mappo_dual_update_slabs(B);
+#ifdef MLP_STAMPS
+  a.stamps = c.stamps = nullptr;
+#endif
+  dim3 grid((unsigned)(d.nA + d.nC)), block(2 * WAVE * np);
+  const bool wa = a.desc.in_dim > 32, wc = c.desc.in_dim > 32, relu = a.desc.use_relu != 0;
+  int rc;
+  switch (a.desc.layer_N) {
+    case 0: rc = relu ? upd2d_inst<true, 0>(wa, wc, grid, block, lds_bytes, as_stream(stream), d) : upd2d_inst<false, 0>(wa, wc, grid, block, lds_bytes, as_stream(stream), d); break;
+    case 1: rc = relu ? upd2d_inst<true, 1>(wa, wc, grid, block, lds_bytes, as_stream(stream), d) : upd2d_inst<false, 1>(wa, wc, grid, block, lds_bytes, as_stream(stream), d); break;
+    default: rc = relu ? upd2d_inst<true, 2>(wa, wc, grid, block, lds_bytes, as_stream(stream), d) : upd2d_inst<false, 2>(wa, wc, grid, block, lds_bytes, as_stream(stream), d); break;
+  }
+  if (rc) return rc;
+  MAPPO_CHECK_LAUNCH("actor_critic_update");
+  return MAPPO_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -375,17 +375,17 @@ __device__ __forceinline__ void raw_to_grad1(f32x16 (&g)[NTJ], const float (&w)[
 // vector ids of the per-wave vector partials (epilogue): b1 ln1_w ln1_b | (b2 ln2_w ln2_b) x LN | bh | fn_w fn_b
 template <int LN> struct VecIds { static constexpr int BH = 3 * (LN + 1), FNW = BH + 1, FNB = BH + 2, N = BH + 3; };
 
+// Workgroup `bid` of the `nb` workgroups that share this network's B rows (blockIdx / gridDim of a plain launch; a
+// sub-range of the grid in the dual launch below).  red_smem: 64 doubles, pair_cnt: 4 words of static LDS.
 template <bool RELU, int LN, int HEAD, bool WIDE>
-__global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
-  extern __shared__ __align__(16) float lds[];
-  __shared__ double red_smem[16 * 4];
+__device__ __forceinline__ void update2_body(const UpdArgs &p, float *lds, double *red_smem, unsigned *pair_cnt, const int bid,
+                                             const int nb) {
   const NetOff &o = p.off;
   const LdsMap &m = p.map;
   const int n_pairs = blockDim.x / (2 * WAVE);
   const int lane = threadIdx.x & (WAVE - 1), l31 = lane & 31, half = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // wave-uniform: tile indices and bases stay scalar
   const int pair = wave >> 1, fh = wave & 1, row0 = 32 * fh;     // partners sit on different SIMDs; a SIMD hosts two TILES
-  __shared__ unsigned pair_cnt[4];
   if (threadIdx.x < 4) pair_cnt[threadIdx.x] = 0u;              // published by the barrier after the weight staging
   PairSync ps = {};
   ps.cnt = pair_cnt + pair;
@@ -397,8 +397,8 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
   // w, w + W, w + 2W, ...  A tile count that is not a multiple of W then leaves its remainder spread over ALL CUs
   // (first the pairs 0, then the pairs 1, ...) instead of a few workgroups running one more full round.
   const int64_t n_tiles = (p.B + TS - 1) / TS;
-  const int64_t tile_stride = (int64_t)gridDim.x * n_pairs;
-  const int64_t tile0 = (int64_t)pair * gridDim.x + blockIdx.x;
+  const int64_t tile_stride = (int64_t)nb * n_pairs;
+  const int64_t tile0 = (int64_t)pair * nb + bid;
   HalfPrefetch<WIDE> pf;
   LossPrefetch lp;
   STAMP_DECL
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
     if (threadIdx.x == 0) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        double *q = p.partials + (size_t)blockIdx.x * 4 + k;
+        double *q = p.partials + (size_t)bid * 4 + k;
         *q = p.cfg.accumulate_partials ? *q + lacc[k] : lacc[k];
       }
     }
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
   }
   __syncthreads();
   STAMP(12);    // block reduction through LDS
-  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
+  float *slab = p.slabs + (size_t)bid * p.slab_stride + p.slab_col0;
   if (n_reg > 1) {
     for (int e = threadIdx.x; e < P; e += blockDim.x) slab[e] = red0[e] + red0[P + e];
   } else {
@@ -732,4 +732,31 @@ __global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
   st_acc_[14] = ps.cyc;      // (informational: contained in the phases above)
 #endif
   STAMP_FLUSH();
+}
+
+template <bool RELU, int LN, int HEAD, bool WIDE>
+__global__ __launch_bounds__(512, 1) void mlp_update2_kernel(UpdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ double red_smem[16 * 4];
+  __shared__ unsigned pair_cnt[4];
+  update2_body<RELU, LN, HEAD, WIDE>(p, lds, red_smem, pair_cnt, blockIdx.x, gridDim.x);
+}
+
+// Actor AND critic update in ONE launch: workgroups [0, nA) run the actor's update (HEAD 1), [nA, nA + nC) the critic's
+// (HEAD 2).  Each network alone leaves the chip with a ragged tail (2 400 tiles on 1 024 pair-workers: 2.3 rounds of
+// work take 3 rounds of time, twice per PPO update, plus two staging / epilogue phases); side by side on half the CUs
+// each they take 5 rounds and one staging / epilogue phase.  The two bodies share nothing (own slab columns, own
+// loss partials), so nothing needs ordering inside the launch.
+struct DualArgs {
+  UpdArgs a, c;
+  int nA, nC;
+};
+template <bool RELU, int LN, bool WIDE_A, bool WIDE_C>
+__global__ __launch_bounds__(512, 1) void mlp_update2_dual_kernel(DualArgs d) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ double red_smem[16 * 4];
+  __shared__ unsigned pair_cnt[4];
+  const int bid = blockIdx.x;
+  if (bid < d.nA) update2_body<RELU, LN, 1, WIDE_A>(d.a, lds, red_smem, pair_cnt, bid, d.nA);
+  else update2_body<RELU, LN, 2, WIDE_C>(d.c, lds, red_smem, pair_cnt, bid - d.nA, d.nC);
 }
