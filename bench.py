@@ -31,7 +31,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-HBM_TRAFFIC_CRITIC_UPDATE_BYTES = 2 * 9008 * 1024 + 8124 * 1024     # measured offline, see roofline.traffic_note
+HBM_TRAFFIC_CRITIC_UPDATE_BYTES = 2 * 9008 * 1024 + 8124 * 1024     # measured offline (rocprofv3 PMC), profiles/r01/g_update_kernels_hbm_pmc.csv
+HBM_TRAFFIC_DUAL_UPDATE_BYTES = HBM_TRAFFIC_CRITIC_UPDATE_BYTES + 2 * 4498 * 1024 + 6008 * 1024
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 
 
@@ -143,6 +144,7 @@ def install_timer(timer):
     for name, kernel, label in (("ppo_loss_fwd_bwd", "ppo_loss", "ppo_loss"), ("mlp_backward", "mlp_bwd", "mlp_backward"),
                                 ("actor_update", "mlp_bwd", "actor_update"), ("critic_update", "mlp_bwd", "critic_update"),
                                 ("mlp_forward", "mlp_fwd", "mlp_forward"), ("gae_scan", "gae", "gae_scan"),
+                                ("actor_critic_update", "mlp_bwd", "actor_critic_update"), ("reduce_clip_adam", "slab_reduce", "slab_reduce"),
                                 ("slab_reduce", "slab_reduce", "slab_reduce"), ("actor_act", "act", "actor_act"),
                                 ("rollout_step", "act", "rollout_step")):
         orig = getattr(ops, name)
@@ -244,7 +246,7 @@ def main():
     # the hot kernels carries HIP events (hipGraph replays cannot be instrumented from the host) ----
     graph_flags = (runner._use_graph, runner.trainer._use_graph)
     runner._use_graph = runner.trainer._use_graph = False
-    labels = ["actor_update", "critic_update", "rollout_step", "mlp_forward", "gae_scan", "slab_reduce", "actor_act", "ppo_loss",
+    labels = ["actor_critic_update", "actor_update", "critic_update", "rollout_step", "mlp_forward", "gae_scan", "slab_reduce", "actor_act", "ppo_loss",
               "mlp_backward"]
     timer.active = set(labels)
     for i in range(2):
@@ -259,20 +261,29 @@ def main():
     S = per_gpu_steps // args.num_mini_batch                 # samples per update-kernel launch
     H = 64
     macs_critic = D * M * H + H * H + H                     # forward MACs per sample (share_obs 54 -> 64 -> 64 -> 1)
+    macs_actor = D * H + H * H + H * A                      # obs 18 -> 64 -> 64 -> 5
     roofline = None
-    if kern.get("critic_update"):
+    note = ("algorithmic flops = 6 x forward MACs per sample (forward, dW, dX; SURVEY.md 8d); the kernel issues fewer: the input "
+            "layer needs no dX (feature-norm gradients come from the dW products)")
+    if kern.get("actor_critic_update"):
+        us = kern["actor_critic_update"]
+        flops = S * 6 * (macs_critic + macs_actor)
+        achieved = flops / (us * 1e-6) / 1e12
+        roofline = dict(bound="mfma", kernel="mlp_update2_dual_kernel<relu, layer_N=1> (actor HEAD 1 + critic HEAD 2 in one launch)",
+                        achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS,
+                        traffic=HBM_TRAFFIC_DUAL_UPDATE_BYTES if (S == 76800 and args.num_mini_batch == 1) else None,
+                        traffic_note="HBM bytes per launch = sum of the two networks' single launches measured with rocprofv3 PMC passes "
+                                     "(profiles/r01/g_update_kernels_hbm_pmc.csv): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE; "
+                                     "the dual launch writes half the slab rows, so its write traffic is at most this",
+                        flops_per_launch=flops, launch_us=us, note=note)
+    elif kern.get("critic_update"):
         us = kern["critic_update"]
         flops = S * 6 * macs_critic                          # forward + dW + dX, 2 flop per MAC
         achieved = flops / (us * 1e-6) / 1e12
         roofline = dict(bound="mfma", kernel="mlp_update2_kernel<relu, layer_N=1, HEAD=critic, wide>", achieved=achieved,
                         peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS,
                         traffic=HBM_TRAFFIC_CRITIC_UPDATE_BYTES if (S == 76800 and args.num_mini_batch == 1) else None,
-                        traffic_note="HBM bytes per launch from rocprofv3 PMC passes of this workload (profiles/r01/g_update_kernels_hbm_pmc.csv): "
-                                     "2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE = 18.4 MB + 8.3 MB; compulsory bytes: 16.6 MB rows + "
-                                     "0.9 MB loss inputs + 8.3 MB gradient slabs",
-                        flops_per_launch=flops, launch_us=us,
-                        note="algorithmic flops = 6 x forward MACs per sample (forward, dW, dX; SURVEY.md 8d); the kernel issues "
-                             "fewer: the input layer needs no dX (feature-norm gradients come from the dW products)")
+                        flops_per_launch=flops, launch_us=us, note=note)
     loss_roof = ppo_loss_roofline(runner, timer, A)
     out = dict(metric="agent-steps/sec (collect+GAE+PPO), MPE simple_spread 3-agent", value=value, unit="agent-steps/s",
                n_gpus=world, steps=ns.steps, warmup=ns.warmup, ms_per_step=1e3 * dt / ns.steps, higher_is_better=True,
