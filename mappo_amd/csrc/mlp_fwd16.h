@@ -1,0 +1,162 @@
+// mlp_fwd16.h — rollout forward on v_mfma_f32_16x16x4_f32: one wave per 16 samples, the whole trunk in registers.
+//
+// The rollout step runs the networks on a few thousand rows (3 072 at BASELINE config 2): one tile per wave, so what
+// counts is the LENGTH of the dependent chain, not throughput.  With the 32x32x2 tiles of mlp_forward_kernel a layer is
+// 32 k-steps, each an LDS round trip (weights and the previous layer's xhat tile) before its two MFMAs.  Here:
+//   * 16x16x4 MFMAs: a layer is 16 k-groups of four independent accumulators (the 4 x 16 output features);
+//   * in the 16x16 accumulator layout lane (j = lane & 15, q = lane >> 4) holds features 16 b + 4 q + r (b, r = 0..3) of
+//     sample j.  The B operand of a k-group needs ONE feature per q for sample j — and the reduction order over k is
+//     free, so k-group (b, r) takes k = 16 b + 4 q + r: exactly the value the lane already holds.  The activations never
+//     leave the registers: no xhat tiles, no LDS synchronisation inside the trunk; only the weights are read from LDS
+//     (A operand, row k of the k-major copy);
+//   * LayerNorm: 16 values per lane, the 4 lanes of a sample combine with two permlane swaps;
+//   * input rows: lane (j, q) loads features k = 4 g + q of its sample, which is the B operand of layer 1 as it is.
+// Same arithmetic as mlp_forward_kernel up to the order of the fp32 sums.
+#pragma once
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ float quad_sum16(float v) { return xhalf_sum(xrow_sum(v)); }     // lanes j, j+16, j+32, j+48
+
+// act + LayerNorm(64) of acc[b][r] (feature 16 b + 4 q + r) -> h = xhat * gamma + beta (the next layer's B operands)
+template <bool RELU>
+__device__ __forceinline__ void act_ln16(f32x4 (&acc)[4], const float *sG, const float *sBt, int q) {
+  float s = 0.f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[b][r] = act_fwd<RELU>(acc[b][r]); s += acc[b][r]; }
+  const float mean = quad_sum16(s) * (1.f / HID);
+  float v = 0.f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float c = acc[b][r] - mean; v += c * c; }
+  const float rstd = 1.0f / sqrtf(quad_sum16(v) * (1.f / HID) + LN_EPS);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const float4 g = *reinterpret_cast<const float4 *>(sG + 16 * b + 4 * q), t = *reinterpret_cast<const float4 *>(sBt + 16 * b + 4 * q);
+    acc[b][0] = (acc[b][0] - mean) * rstd * g.x + t.x;
+    acc[b][1] = (acc[b][1] - mean) * rstd * g.y + t.y;
+    acc[b][2] = (acc[b][2] - mean) * rstd * g.z + t.z;
+    acc[b][3] = (acc[b][3] - mean) * rstd * g.w + t.w;
+  }
+}
+
+// out[bo] (features 16 bo + .., bo < NB) = bias + W . h, h in registers (feature 16 b + 4 q + r); sW k-major, row stride ws
+template <int NB>
+__device__ __forceinline__ void layer16(f32x4 (&out)[NB], const f32x4 (&h)[4], const float *sW, int ws, const float *sB, int j, int q) {
+#pragma unroll
+  for (int bo = 0; bo < NB; ++bo) {
+    const float4 bv = *reinterpret_cast<const float4 *>(sB + 16 * bo + 4 * q);
+    out[bo][0] = bv.x; out[bo][1] = bv.y; out[bo][2] = bv.z; out[bo][3] = bv.w;
+  }
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float *row = sW + (16 * b + 4 * q + r) * ws + j;
+#pragma unroll
+      for (int bo = 0; bo < NB; ++bo) out[bo] = mfma16(row[16 * bo], h[b][r], out[bo]);
+    }
+}
+
+// workgroup `bid` of `nb`; MODE 0: out[i] = value (critic, out_dim 1) | MODE 1: sample / argmax + log-prob (actor)
+template <bool RELU, int LN, int MODE>
+__device__ __forceinline__ void forward16_body(const FwdArgs &p, float *lds, const int bid, const int nb) {
+  const int n_waves = blockDim.x / WAVE;
+  const NetOff &o = p.off;
+  const LdsMap &m = p.map;
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), j = lane & 15, q = lane >> 4;
+  const int D = p.desc.in_dim, Dp = (D + 1) & ~1, A = p.desc.out_dim;
+  const int NG = (D + 3) >> 2;                                   // k-groups of the input layer
+  const int64_t n_tiles = (p.B + 15) / 16;
+  const bool fnorm = p.desc.use_feature_norm != 0;
+  const float inv_D = 1.0f / (float)D;
+  float *tZ = lds + m.tiles + wave * m.wave_stride;              // [16][TP] logits of this wave's samples (MODE 1)
+  bool staged = false;
+  for (int64_t tile = (int64_t)bid * n_waves + wave; tile < n_tiles || !staged; tile += (int64_t)nb * n_waves) {
+    const int64_t i = tile * 16 + j;
+    const bool ok = tile < n_tiles && i < p.B;
+    const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
+    const int64_t off = p.x_M ? (row / p.x_M) * p.x_sn + (row % p.x_M) * p.x_sm : row * D;
+    // ---- input rows: features 4 g + q of sample j (unconditional clamped loads, all in flight under the weight staging) ----
+    float xin[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) xin[g] = p.x[off + min(4 * g + q, D - 1)];
+    if (!staged) {                                               // first pass: stage the weights under the row loads
+      stage_all_weights<LN>(lds, m, p.params, o, p.desc);
+      __syncthreads();
+      staged = true;
+      if (tile >= n_tiles) break;                                // a wave without a tile only helped staging
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) xin[g] = (ok && 4 * g + q < D) ? xin[g] : 0.f;
+    if (fnorm) {
+      float s = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) s += xin[g];
+      const float mean = quad_sum16(s) * inv_D;
+      float v = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) { const float c = (4 * g + q < D) ? xin[g] - mean : 0.f; v += c * c; }
+      const float rstd = 1.0f / sqrtf(quad_sum16(v) * inv_D + LN_EPS);
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const int k = min(4 * g + q, D - 1);
+        xin[g] = (4 * g + q < D) ? (xin[g] - mean) * rstd * lds[m.fn_w + k] + lds[m.fn_b + k] : 0.f;
+      }
+    }
+    // ---- layer 1: k-group g = input features 4 g + q ----
+    f32x4 h[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float4 bv = *reinterpret_cast<const float4 *>(lds + m.b1 + 16 * b + 4 * q);
+      h[b][0] = bv.x; h[b][1] = bv.y; h[b][2] = bv.z; h[b][3] = bv.w;
+    }
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      if (g < NG) {                                                             // wave-uniform
+        const float *rowp = lds + m.w1 + min(4 * g + q, Dp - 1) * WP + j;      // rows >= D carry xin = 0
+#pragma unroll
+        for (int b = 0; b < 4; ++b) h[b] = mfma16(rowp[16 * b], xin[g], h[b]);
+      }
+    }
+    act_ln16<RELU>(h, lds + m.ln1_w, lds + m.ln1_b, q);
+#pragma unroll
+    for (int l = 0; l < LN; ++l) {
+      f32x4 h2[4];
+      layer16<4>(h2, h, lds + m.w2[l], WP, lds + m.b2[l], j, q);
+      act_ln16<RELU>(h2, lds + m.ln2_w[l], lds + m.ln2_b[l], q);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) h[b] = h2[b];
+    }
+    // ---- head ----
+    if (MODE == 0) {
+      f32x4 z[1];
+      layer16<1>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
+      if (ok && q == 0) p.out[i] = z[0][0];                                      // out_dim 1: row a = 0 sits in (q = 0, r = 0)
+    } else {
+      f32x4 z[2];
+      layer16<2>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
+#pragma unroll
+      for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a = 16 * bo + 4 * q + r;
+          if (a < A) tZ[j * TP + a] = z[bo][r];
+        }
+      wave_lds_sync();
+      if (ok && q == 0) {
+        const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+        float action, logp;
+        categorical_act_lane(tZ + j * TP, A, p.avail ? p.avail + i * A : nullptr, p.deterministic != 0, p.seed, ctr, (uint64_t)i, action, logp);
+        p.actions[i] = action;
+        p.logp[i] = logp;
+      }
+      wave_lds_sync();
+    }
+  }
+}

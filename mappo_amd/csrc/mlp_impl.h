@@ -600,12 +600,13 @@ struct StepArgs {
   InsertArgs ins;
   int nA, nC, nI;
 };
-template <bool RELU, int LN, int XWA, int XWC>
+#include "mlp_fwd16.h"
+template <bool RELU, int LN>
 __global__ __launch_bounds__(256, 1) void rollout_step_kernel(StepArgs s) {
   extern __shared__ __align__(16) float lds[];
   const int bid = blockIdx.x;
-  if (bid < s.nA) forward_body<RELU, LN, 1, XWA>(s.a, lds, bid, s.nA);
-  else if (bid < s.nA + s.nC) forward_body<RELU, LN, 0, XWC>(s.c, lds, bid - s.nA, s.nC);
+  if (bid < s.nA) forward16_body<RELU, LN, 1>(s.a, lds, bid, s.nA);
+  else if (bid < s.nA + s.nC) forward16_body<RELU, LN, 0>(s.c, lds, bid - s.nA, s.nC);
   else insert_mpe_body(s.ins, bid - s.nA - s.nC, s.nI);
 }
 
@@ -1293,22 +1294,16 @@ static int fit_waves(const mappo_net_desc &d, int want) {
 
 #ifdef MLP_TU_STEP
 // ---- fused rollout step (rollout_step_kernel): translation unit mlp_step.hip --------------------------------------
-template <bool R, int L, int XA, int XC>
+template <bool R, int L>
 static int step_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const StepArgs &a) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)rollout_step_kernel<R, L, XA, XC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)LDS_DYN_MAX);
+    hipError_t e_ = hipFuncSetAttribute((const void *)rollout_step_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
     if (e_ != hipSuccess) { mappo_set_error("rollout_step: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
     attr_set = true;
   }
-  PROF_LAUNCH(MAPPO_PROF_ACT, (rollout_step_kernel<R, L, XA, XC>), grid, block, lds_bytes, st, a);
+  PROF_LAUNCH(MAPPO_PROF_ACT, (rollout_step_kernel<R, L>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
-}
-template <bool R, int L>
-static int step_dispatch(int xa, int xc, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const StepArgs &a) {
-  if (xa == 0) return xc == 0 ? step_launch<R, L, 0, 0>(grid, block, lds_bytes, st, a) : step_launch<R, L, 0, 1>(grid, block, lds_bytes, st, a);
-  return xc == 0 ? step_launch<R, L, 1, 0>(grid, block, lds_bytes, st, a) : step_launch<R, L, 1, 1>(grid, block, lds_bytes, st, a);
 }
 
 extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_desc *actor_desc, const float *critic_params,
@@ -1330,7 +1325,7 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
   MAPPO_REQUIRE(M > 0 || !obs_dst, "rollout_step: the fused insert needs the (thread, agent) row layout (M > 0)");
   MAPPO_REQUIRE(!obs_dst || (share_dst && rewards && dones && rew_dst && mask_dst && B % M == 0), "rollout_step: incomplete insert arguments");
   MAPPO_CLEAR_STICKY();
-  const int64_t n_tiles = (B + TS - 1) / TS;
+  const int64_t n_tiles = (B + 15) / 16;                 // forward16_body: 16 samples per wave
   const int want = n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1);
   int nw = fit_waves(*actor_desc, want);
   const int nwc = fit_waves(*critic_desc, want);
@@ -1359,13 +1354,12 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
     s.nI = (int)(ni > 64 ? 64 : ni);
   }
   dim3 grid((unsigned)(s.nA + s.nC + s.nI)), block(WAVE * nw);
-  const int xa = actor_desc->in_dim > 32 ? 1 : 0, xc = critic_desc->in_dim > 32 ? 1 : 0;
   const bool relu = actor_desc->use_relu != 0;
   int rc;
   switch (actor_desc->layer_N) {
-    case 0: rc = relu ? step_dispatch<true, 0>(xa, xc, grid, block, lds_bytes, as_stream(stream), s) : step_dispatch<false, 0>(xa, xc, grid, block, lds_bytes, as_stream(stream), s); break;
-    case 1: rc = relu ? step_dispatch<true, 1>(xa, xc, grid, block, lds_bytes, as_stream(stream), s) : step_dispatch<false, 1>(xa, xc, grid, block, lds_bytes, as_stream(stream), s); break;
-    default: rc = relu ? step_dispatch<true, 2>(xa, xc, grid, block, lds_bytes, as_stream(stream), s) : step_dispatch<false, 2>(xa, xc, grid, block, lds_bytes, as_stream(stream), s); break;
+    case 0: rc = relu ? step_launch<true, 0>(grid, block, lds_bytes, as_stream(stream), s) : step_launch<false, 0>(grid, block, lds_bytes, as_stream(stream), s); break;
+    case 1: rc = relu ? step_launch<true, 1>(grid, block, lds_bytes, as_stream(stream), s) : step_launch<false, 1>(grid, block, lds_bytes, as_stream(stream), s); break;
+    default: rc = relu ? step_launch<true, 2>(grid, block, lds_bytes, as_stream(stream), s) : step_launch<false, 2>(grid, block, lds_bytes, as_stream(stream), s); break;
   }
   if (rc) return rc;
   MAPPO_CHECK_LAUNCH("rollout_step");

@@ -617,13 +617,23 @@ def test_rollout_step_fused_matches_separate_launches(ops, centralized):
                rew_dst=rd1, mask_dst=md1, centralized=centralized)
     ops.rollout_step(pa, da, pc, dc, (obs, obs.stride(0), obs.stride(1)), (obs, obs.stride(0), 0 if centralized else obs.stride(1)), M, R,
                      None, False, 1234, 7, None, act1, lp1, v1, ins)
-    for a_, b_ in ((od, od1), (sd, sd1), (rd, rd1), (md, md1), (act0, act1), (lp0, lp1), (v0.view(R), v1)):
+    for a_, b_ in ((od, od1), (sd, sd1), (rd, rd1), (md, md1)):
         np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+
+    def same_policy_outputs(act, lp, v):
+        # the step kernel runs the networks on 16x16x4 MFMA tiles (mlp_fwd16.h): same arithmetic, different order of the
+        # fp32 sums, so values / log-probs agree to rounding and a sampled action may flip only at a CDF boundary
+        same = (act == act0).float().mean().item()
+        assert same >= 0.99, same
+        keep = (act == act0).cpu().numpy()
+        np.testing.assert_allclose(lp.cpu().numpy()[keep], lp0.cpu().numpy()[keep], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(v.cpu().numpy(), v0.view(R).cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+    same_policy_outputs(act1, lp1, v1)
     # without the insert, reading the (contiguous) slots
     act2, lp2, v2 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
     ops.rollout_step(pa, da, pc, dc, (od, 0, 0), (sd, 0, 0), 0, R, None, False, 1234, 7, None, act2, lp2, v2, None)
-    for a_, b_ in ((act0, act2), (lp0, lp2), (v0.view(R), v2)):
-        np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+    same_policy_outputs(act2, lp2, v2)
 
 
 def test_reduce_clip_adam_matches_slab_reduce_then_clip_adam(ops):
@@ -676,8 +686,9 @@ def test_rollout_step_values_only_and_copy_batch(ops):
     ins = dict(obs_dst=od1, share_dst=sd1, rewards=(rew, rew.stride(0), rew.stride(1)), dones=(dones, dones.stride(0), dones.stride(1)),
                rew_dst=rd1, mask_dst=md1, centralized=True)
     ops.rollout_step(pa, da, pc, dc, (obs, obs.stride(0), obs.stride(1)), (obs, obs.stride(0), 0), M, R, None, False, 0, 0, None, None, None, v1, ins)
-    for a_, b_ in ((od, od1), (sd, sd1), (rd, rd1), (md, md1), (v0.view(R), v1)):
+    for a_, b_ in ((od, od1), (sd, sd1), (rd, rd1), (md, md1)):
         np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+    np.testing.assert_allclose(v1.cpu().numpy(), v0.view(R).cpu().numpy(), rtol=2e-5, atol=2e-6)
     srcs = [torch.randn(n, device="cuda", generator=g) for n in (7, 1024, 4099, 12)]
     dsts = [torch.zeros_like(t) for t in srcs]
     ops.copy_batch(list(zip(dsts, srcs)))
