@@ -87,7 +87,7 @@ __device__ __forceinline__ void forward16_body(const FwdArgs &p, float *lds, con
 #pragma unroll
     for (int g = 0; g < 16; ++g) xin[g] = p.x[off + min(4 * g + q, D - 1)];
     if (!staged) {                                               // first pass: stage the weights under the row loads
-      stage_all_weights<LN>(lds, m, p.params, o, p.desc);
+      stage_all_weights_1shot<LN>(lds, m, p.params, o, p.desc);
       __syncthreads();
       staged = true;
       if (tile >= n_tiles) break;                                // a wave without a tile only helped staging

@@ -183,6 +183,94 @@ __device__ __forceinline__ void stage_all_weights(float *lds, const LdsMap &m, c
   }
 }
 
+// One-shot variant for in_dim <= 64 and >= 256 threads: EVERY global load of the staging (vectors, W1, W2.., head) is
+// issued before the first LDS store, so a thread pays one memory latency for the whole network instead of one per
+// matrix (four to five dependent L2 / Infinity-Cache round trips otherwise — a large part of a rollout-sized launch).
+// Falls back to stage_all_weights when the float4 views are not available (odd in_dim, unaligned params, small block).
+template <int LN>
+__device__ __forceinline__ void stage_all_weights_1shot(float *lds, const LdsMap &m, const float *__restrict__ params,
+                                                        const NetOff &o, const mappo_net_desc &d) {
+  const int D = d.in_dim, Dp = (D + 1) & ~1, A = d.out_dim;
+  const int nthr = blockDim.x, tid = threadIdx.x;
+  const int FN = m.fn_size;
+  const int n_vec = 2 * FN + 3 * HID * (1 + LN) + 32;
+  if (nthr < 256 || (D & 1) || D > MAXD || ((((uintptr_t)params) & 15) != 0) || n_vec > 4 * nthr) {
+    stage_all_weights<LN>(lds, m, params, o, d);
+    return;
+  }
+  // ---- loads ----
+  const float4 *g1 = reinterpret_cast<const float4 *>(params + o.w1), *gh = reinterpret_cast<const float4 *>(params + o.wh);
+  const int n4_1 = 16 * D, n4_h = 16 * A;
+  float4 w1v[4], w2v[LN > 0 ? LN : 1][4], whv[2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) w1v[j] = g1[min(j * nthr + tid, n4_1 - 1)];
+#pragma unroll
+  for (int l = 0; l < LN; ++l) {
+    const float4 *g2 = reinterpret_cast<const float4 *>(params + o.w2[l]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w2v[l][j] = g2[min(j * nthr + tid, 1023)];
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) whv[j] = gh[min(j * nthr + tid, n4_h - 1)];
+  float vv[4]; int vdst[4]; bool vwr[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int e = j * nthr + tid;
+    int src = -1; float fill = 0.f; int dst = m.fn_w;
+    vwr[j] = e < n_vec;
+    if (e < FN) { dst = m.fn_w + e; if (d.use_feature_norm) { if (e < D) src = o.fn_w + e; } else fill = e < D ? 1.f : 0.f; }
+    else if (e < 2 * FN) { const int i = e - FN; dst = m.fn_b + i; if (d.use_feature_norm && i < D) src = o.fn_b + i; }
+    else if (e < 2 * FN + 3 * HID) { const int i = e - 2 * FN; dst = m.b1 + i; src = o.b1 + i; }
+    else if (e < 2 * FN + 3 * HID * (1 + LN)) {
+      const int i = e - 2 * FN - 3 * HID, l = i / (3 * HID), r = i - l * 3 * HID;
+      dst = (l == 0 ? m.b2[0] : m.b2[LN > 1 ? 1 : 0]) + r;
+      src = (l == 0 ? o.b2[0] : o.b2[LN > 1 ? 1 : 0]) + r;
+    } else { const int i = e - 2 * FN - 3 * HID * (1 + LN); dst = m.bh + i; if (i < A) src = o.bh + i; }
+    const float ld = params[src >= 0 ? src : 0];
+    vv[j] = src >= 0 ? ld : fill;
+    vdst[j] = dst;
+  }
+  // ---- stores ----
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = j * nthr + tid;
+    if (i < n4_1) {
+      const int e = i << 2;
+      int f = e / D, k = e - f * D;
+      const float t[4] = {w1v[j].x, w1v[j].y, w1v[j].z, w1v[j].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        lds[m.w1 + k * WP + f] = t[c];
+        if (++k == D) { k = 0; ++f; }
+      }
+    }
+  }
+  for (int e = tid; e < HID * (Dp - D); e += nthr) lds[m.w1 + (D + e / HID) * WP + (e % HID)] = 0.f;
+#pragma unroll
+  for (int l = 0; l < LN; ++l)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = j * nthr + tid;
+      if (i < 1024) {
+        const int e = i << 2, f = e >> 6, k = e & 63;
+        float *q = lds + m.w2[l] + k * WP + f;
+        q[0] = w2v[l][j].x; q[WP] = w2v[l][j].y; q[2 * WP] = w2v[l][j].z; q[3 * WP] = w2v[l][j].w;
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = j * nthr + tid;
+    if (i < n4_h) {
+      const int e = i << 2, a = e >> 6, k = e & 63;
+      float *q = lds + m.wh + k * HP + a;
+      q[0] = whv[j].x; q[HP] = whv[j].y; q[2 * HP] = whv[j].z; q[3 * HP] = whv[j].w;
+    }
+  }
+  for (int e = tid; e < HID * (32 - A); e += nthr) { const int k = e / (32 - A), a = A + e - k * (32 - A); lds[m.wh + k * HP + a] = 0.f; }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) if (vwr[j]) lds[vdst[j]] = vv[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // input rows.  Lane (s = lane & 31, half = lane >> 5) fetches features k = 2j + half of sample s of the NEXT tile
 // into registers (NV = ceil(D/2) <= 16 | 32); at the top of the tile the LayerNorm over the D input features

@@ -409,7 +409,7 @@ __device__ __forceinline__ void update2_body(const UpdArgs &p, float *lds, doubl
     const int64_t row = (lane < nv) ? (p.rows ? (int64_t)p.rows[base0 + lane] : base0 + lane) : 0;
     if (fh == 0) prefetch_loss<HEAD>(lp, p, row, nv, lane, A); else { lp.f0 = lp.f1 = lp.f2 = lp.f3 = 0.f; lp.dead = 0u; }
   }
-  stage_all_weights<LN>(lds, m, p.params, o, p.desc);
+  stage_all_weights_1shot<LN>(lds, m, p.params, o, p.desc);
   __syncthreads();
 #ifndef EXP_NOFOLDPASS
   fold_affine<LN, HEAD>(lds, m, D, Dp, wave, blockDim.x / WAVE, lane);
