@@ -484,6 +484,19 @@ def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, wit
     ops.update_stats(part_a, ns, part_c, ns, mom, cfg, stats_f)
     grad_f = torch.zeros(P, device="cuda")
     ops.slab_reduce(slabs, ns, P, P, grad_f)
+    # (1b) both networks in ONE launch (mappo_actor_critic_update), in_dim <= 64
+    if D <= 64 and S <= 64:
+        nd = ops.dual_update_slabs(B)
+        slabs_d = torch.zeros(nd, P, device="cuda")
+        pda, pdc = ops.update_partials("cuda"), ops.update_partials("cuda")
+        ops.actor_critic_update(pa, da, g["obs"], pc, dc, g["sobs"], d_rows, B, g["avail"], g["actions"], g["old"], g["adv"], g["active"],
+                                g["vold"], g["ret"], g["vn"], mom, cfg, slabs_d, P, 0, col_c, pda, pdc)
+        stats_d = torch.zeros(6, dtype=torch.float64, device="cuda")
+        ops.update_stats(pda, nd, pdc, nd, mom, cfg, stats_d)
+        grad_d = torch.zeros(P, device="cuda")
+        ops.slab_reduce(slabs_d, nd, P, P, grad_d)
+        close(stats_d, stats_f, 1e-9, 1e-12, "stats dual vs separate launches")
+        close_rel_max(grad_d, grad_f.cpu().numpy(), 2e-6, "grad dual vs separate launches")
     # (2) unfused
     logits, values = torch.zeros(B, A, device="cuda"), torch.zeros(B, device="cuda")
     ops.mlp_forward(pa, da, g["obs"], d_rows, B, logits)
@@ -694,3 +707,29 @@ def test_rollout_step_values_only_and_copy_batch(ops):
     ops.copy_batch(list(zip(dsts, srcs)))
     for a_, b_ in zip(srcs, dsts):
         np.testing.assert_array_equal(a_.cpu().numpy(), b_.cpu().numpy())
+
+
+@pytest.mark.parametrize("Da,Dc,A,LN,relu,fnorm,R", [(1, 1, 1, 1, True, True, 5), (64, 64, 32, 2, False, False, 130), (33, 7, 9, 0, True, True, 47),
+                                                      (18, 54, 5, 1, False, True, 3072), (20, 60, 17, 2, True, False, 16)])
+def test_rollout_step_shapes_vs_forward_kernels(ops, Da, Dc, A, LN, relu, fnorm, R):
+    """The 16x16x4 step kernel against mlp_forward / actor_act over network shapes (odd / maximal widths, partial tiles,
+    tanh, no feature norm): values and deterministic log-probs to fp32 rounding, argmax actions equal unless two logits tie
+    to rounding."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    da = ops.net_desc(Da, A, layer_N=LN, use_relu=relu, use_feature_norm=fnorm)
+    dc = ops.net_desc(Dc, 1, layer_N=LN, use_relu=relu, use_feature_norm=fnorm)
+    pa = torch.randn(ops.net_param_count(da), device="cuda", generator=g) * 0.3
+    pc = torch.randn(ops.net_param_count(dc), device="cuda", generator=g) * 0.3
+    obs = torch.randn(R, Da, device="cuda", generator=g)
+    sh = torch.randn(R, Dc, device="cuda", generator=g)
+    avail = (torch.rand(R, A, device="cuda", generator=g) > 0.3).float()
+    avail[:, 0] = 1.0
+    act0, lp0, v0 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, 1, device="cuda")
+    ops.actor_act(pa, da, obs, avail, R, True, 1, 0, act0, lp0)
+    ops.mlp_forward(pc, dc, sh, None, R, v0)
+    act1, lp1, v1 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    ops.rollout_step(pa, da, pc, dc, (obs, 0, 0), (sh, 0, 0), 0, R, avail, True, 1, 0, None, act1, lp1, v1, None)
+    np.testing.assert_allclose(v1.cpu().numpy(), v0.view(R).cpu().numpy(), rtol=3e-5, atol=3e-6)
+    same = (act1 == act0).cpu().numpy()
+    assert same.mean() >= 0.98, same.mean()
+    np.testing.assert_allclose(lp1.cpu().numpy()[same], lp0.cpu().numpy()[same], rtol=3e-5, atol=3e-6)
