@@ -239,7 +239,15 @@ int mappo_update_stats(const double *actor_partials, int32_t n_actor /*workgroup
 int mappo_mlp_features(const float *params, const mappo_net_desc *desc /*host*/, const float *x, const int32_t *rows,
                        int64_t B, float *featT /*[64][B]*/, mappo_stream_t stream);
 int64_t mappo_gru_scratch_floats(int32_t L, int32_t Nc);
-int mappo_gru_forward(const float *params, const mappo_net_desc *desc /*host*/, const float *featT, const float *h0,
+/* Input-side products of the GRU, outside the sequential kernels (no time dependence: plain row-tile products over all
+ * B = L*Nc rows):  giT [192][B] = W_ih featT + b_ih   and   dxT [64][B] = W_ih^T dgiT.  mappo_gru_forward with giT != NULL
+ * and mappo_gru_backward with dxT == NULL then carry only the W_hh half of the matrix work. */
+int mappo_gru_input_gates(const float *params, const mappo_net_desc *desc /*host*/, const float *featT /*[64][B]*/, int64_t B,
+                          float *giT /*[192][B]*/, mappo_stream_t stream);
+int mappo_gru_input_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *dgiT /*[192][B]*/, int64_t B,
+                             float *dxT /*[64][B]*/, mappo_stream_t stream);
+int mappo_gru_forward(const float *params, const mappo_net_desc *desc /*host*/, const float *featT,
+                      const float *giT /*[192][B] from mappo_gru_input_gates, or NULL: computed in the kernel*/, const float *h0,
                       const int32_t *h0_rows /*[Nc] or NULL*/, const float *masks, const int32_t *rows /*[B] or NULL*/,
                       int32_t L, int32_t Nc, float *h_last /*[Nc][64] or NULL*/, float *scratch /*or NULL*/,
                       int32_t head_mode, float *out, const float *avail /*[B][A] or NULL*/, int32_t deterministic,

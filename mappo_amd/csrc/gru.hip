@@ -35,10 +35,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf
 struct GruLds {
   int wih, whh, wh, bih, bhh, nw, nb, bh, tiles, wave_stride, total;
 };
-__host__ __device__ inline GruLds gru_lds(int n_waves, int wave_rows) {
+__host__ __device__ inline GruLds gru_lds(int n_waves, int wave_rows, bool with_ih = true) {
   GruLds m;
   int p = 0;
-  m.wih = p; p = al4(p + HID * GS);
+  m.wih = p; if (with_ih) p = al4(p + HID * GS);          // not resident when the input products run in their own kernels
   m.whh = p; p = al4(p + HID * GS);
   m.wh = p; p = al4(p + HID * HP);
   m.bih = p; p += NG; m.bhh = p; p += NG;
@@ -170,9 +170,56 @@ __device__ __forceinline__ f32x16 gru_head(const float *lds, const GruLds &m, co
 // ---- one GRU cell step for a tile: gates from x (B operand straight from feature-major HBM) and hm (LDS tile) ----
 struct CellOut { f32x16 r[2], z[2], n[2], ghn[2]; };
 
+// PRE_GI: gi = W_ih x + b_ih comes precomputed (mappo_gru_input_gates: feature-major giT[192][ldx]); the cell then only
+// runs the W_hh products — half the MFMA work of the sequential kernel, and W_ih need not be resident in LDS.
+template <bool PRE_GI>
 __device__ __forceinline__ void gru_cell(CellOut &c, const float *lds, const GruLds &m, const float *__restrict__ xT, int64_t ldx,
                                          int64_t col, bool ok, const float *tHm, int l31, int half) {
   f32x16 arz[4], ain[2], ahn[2];
+  if (PRE_GI) {
+    const int64_t cc = ok ? col : 0;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4 *>(lds + m.bhh + 32 * t + 8 * q + 4 * half);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) arz[t][4 * q + e] = xT[(int64_t)(32 * t + 8 * q + 4 * half + e) * ldx + cc] + bb[e];
+      }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4 *>(lds + m.bhh + 128 + 32 * t + 8 * q + 4 * half);
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ain[t][4 * q + e] = xT[(int64_t)(128 + 32 * t + 8 * q + 4 * half + e) * ldx + cc];
+          ahn[t][4 * q + e] = bb[e];
+        }
+      }
+    const float *sH = lds + m.whh;
+#pragma unroll 4
+    for (int kk = 0; kk < HID / 2; ++kk) {
+      const int k = 2 * kk + half;
+      const float bh = tHm[k * TP + l31];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) arz[t] = mfma(sH[k * GS + 32 * t + l31], bh, arz[t]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) ahn[t] = mfma(sH[k * GS + 128 + 32 * t + l31], bh, ahn[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        c.r[t][r] = sigmoidf_(arz[t][r]);
+        c.z[t][r] = sigmoidf_(arz[2 + t][r]);
+        c.ghn[t][r] = ahn[t][r];
+        c.n[t][r] = tanhf(ain[t][r] + c.r[t][r] * ahn[t][r]);
+      }
+    return;
+  }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -231,6 +278,7 @@ struct GruFwdArgs {
   NetOff off;
   GruLds map;
   const float *xT;            // [64][B] trunk features, B = L*Nc, column t*Nc + c
+  const float *giT;           // optional [192][B] precomputed input gates (training): the cell then skips the W_ih products
   const float *h0;            // [.][64] row-major initial states
   const int32_t *h0_rows;     // [Nc] or NULL (identity)
   const float *masks;         // buffer-order masks, indexed by rows[t*Nc + c] (NULL rows = identity)
@@ -251,7 +299,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
   const GruLds &m = p.map;
   const int n_waves = blockDim.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
-  stage_gru_all(lds, m, p.params, p.off, p.A, true, p.head_mode != 0);
+  stage_gru_all(lds, m, p.params, p.off, p.A, p.giT == nullptr, p.head_mode != 0);
   __syncthreads();
   float *tHm = lds + m.tiles + wave * m.wave_stride;     // [64][TP] masked previous state (B operand)
   float *tN = tHm + HID * TP;                            // [64][TP] normalised state (head input)   (head modes only)
@@ -276,7 +324,8 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
       regs_to_tile64(tHm, hm, l31, half);
       wave_lds_sync();
       CellOut co;
-      gru_cell(co, lds, m, p.xT, B, col, ok, tHm, l31, half);
+      if (p.giT) gru_cell<true>(co, lds, m, p.giT, B, col, ok, tHm, l31, half);
+      else gru_cell<false>(co, lds, m, p.xT, B, col, ok, tHm, l31, half);
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -355,7 +404,7 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
   const NetOff &o = p.off;
   const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
   const int A = p.A;
-  stage_gru_all(lds, m, p.params, o, A, true, true);
+  stage_gru_all(lds, m, p.params, o, A, p.dxT != nullptr, true);
   __syncthreads();
   float *tG = lds + m.tiles;                 // [192][TP]  d gi / d gh (B operand of the W^T products)
   float *tN = tG + NG * TP;                  // [64][TP]   normalised state, then scratch
@@ -501,26 +550,27 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
       // tG <- d gi  [g][s]
       regs_to_tile64(tG, d_r, l31, half);
       regs_to_tile64(tG + HID * TP, d_z, l31, half);
-      regs_to_tile64(tG + 2 * HID * TP, d_n, l31, half);
-      wave_lds_sync();
-      // d x_t = W_ih^T . d gi
-      f32x16 dx[2];
+      if (p.dxT) {                              // d x_t = W_ih^T . d gi here; NULL: deferred to mappo_gru_input_backward
+        regs_to_tile64(tG + 2 * HID * TP, d_n, l31, half);
+        wave_lds_sync();
+        f32x16 dx[2];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dx[tt][r] = 0.f;
-      {
-        const float *sI = lds + m.wih;
+          for (int r = 0; r < 16; ++r) dx[tt][r] = 0.f;
+        {
+          const float *sI = lds + m.wih;
 #pragma unroll 4
-        for (int gg = 0; gg < NG / 2; ++gg) {
-          const int g = 2 * gg + half;
-          const float b = tG[g * TP + l31];
-          dx[0] = mfma(sI[l31 * GS + g], b, dx[0]);
-          dx[1] = mfma(sI[(32 + l31) * GS + g], b, dx[1]);
+          for (int gg = 0; gg < NG / 2; ++gg) {
+            const int g = 2 * gg + half;
+            const float b = tG[g * TP + l31];
+            dx[0] = mfma(sI[l31 * GS + g], b, dx[0]);
+            dx[1] = mfma(sI[(32 + l31) * GS + g], b, dx[1]);
+          }
         }
+        store_fm(p.dxT, B, col, dx, ok, half);
+        wave_lds_sync();
       }
-      store_fm(p.dxT, B, col, dx, ok, half);
-      wave_lds_sync();
       // tG n-rows <- d gh_n ; d hm = W_hh^T . d gh
       regs_to_tile64(tG + 2 * HID * TP, d_hn, l31, half);
       wave_lds_sync();
@@ -661,6 +711,94 @@ __global__ __launch_bounds__(256, 1) void gru_wgrad_kernel(GruWgArgs p) {
   if (lane < 32) slab[boff + 96 * ghalf + 64 + lane] = bacc1;
 }
 
+// ---- input-side products, out of the sequential kernels --------------------------------------------------------------
+// gi = W_ih x + b_ih has no dependence on time, and neither has d x = W_ih^T d gi: both run here as plain row-tile
+// products over all B = L * Nc rows (every CU busy), so that the sequential forward / backward kernels carry only the
+// W_hh half of the MFMA work and keep 49 KB of LDS free (two workgroups — actor's and critic's — fit a CU side by side).
+struct GruInArgs {
+  const float *params;
+  NetOff off;
+  const float *inT;           // gates: xT [64][B]      | backward: dgiT [192][B]
+  float *outT;                // gates: giT [192][B]    | backward: dxT  [64][B]
+  int64_t B;
+};
+
+__global__ __launch_bounds__(256, 1) void gru_gi_kernel(GruInArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
+  const int n_waves = blockDim.x / WAVE;
+  float *sI = lds, *sB = lds + al4(HID * GS);
+  stage_gru_weight(sI, p.params + p.off.gru_wih);
+  for (int e = threadIdx.x; e < NG; e += blockDim.x) sB[e] = p.params[p.off.gru_bih + e];
+  __syncthreads();
+  const int64_t n_tiles = (p.B + TS - 1) / TS;
+  for (int64_t tile = (int64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * n_waves) {
+    const int64_t col = tile * TS + l31;
+    const bool ok = col < p.B;
+    const int64_t cc = ok ? col : 0;
+    float bx[HID / 2];
+#pragma unroll
+    for (int kk = 0; kk < HID / 2; ++kk) bx[kk] = p.inT[(int64_t)(2 * kk + half) * p.B + cc];
+    f32x16 acc[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4 *>(sB + 32 * t + 8 * q + 4 * half);
+        acc[t][4 * q + 0] = b.x; acc[t][4 * q + 1] = b.y; acc[t][4 * q + 2] = b.z; acc[t][4 * q + 3] = b.w;
+      }
+#pragma unroll 4
+    for (int kk = 0; kk < HID / 2; ++kk) {
+      const int k = 2 * kk + half;
+#pragma unroll
+      for (int t = 0; t < 6; ++t) acc[t] = mfma(sI[k * GS + 32 * t + l31], bx[kk], acc[t]);
+    }
+    if (ok) {
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.outT[(int64_t)(32 * t + ROWMAP(r, half)) * p.B + col] = acc[t][r];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void gru_dx_kernel(GruInArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
+  const int n_waves = blockDim.x / WAVE;
+  float *sI = lds;
+  stage_gru_weight(sI, p.params + p.off.gru_wih);
+  __syncthreads();
+  const int64_t n_tiles = (p.B + TS - 1) / TS;
+  for (int64_t tile = (int64_t)blockIdx.x * n_waves + wave; tile < n_tiles; tile += (int64_t)gridDim.x * n_waves) {
+    const int64_t col = tile * TS + l31;
+    const bool ok = col < p.B;
+    const int64_t cc = ok ? col : 0;
+    f32x16 dx[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dx[tt][r] = 0.f;
+    for (int g0 = 0; g0 < NG / 2; g0 += 32) {                 // 3 batches of 32 gate rows per half: loads first, then the MFMAs
+      float b[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) b[j] = p.inT[(int64_t)(2 * (g0 + j) + half) * p.B + cc];
+#pragma unroll 4
+      for (int j = 0; j < 32; ++j) {
+        const int g = 2 * (g0 + j) + half;
+        dx[0] = mfma(sI[l31 * GS + g], b[j], dx[0]);
+        dx[1] = mfma(sI[(32 + l31) * GS + g], b[j], dx[1]);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) p.outT[(int64_t)(32 * tt + ROWMAP(r, half)) * p.B + col] = dx[tt][r];
+    }
+  }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------
 #define LDS_LIMIT (160 * 1024)
 #define LDS_DYN_MAX (LDS_LIMIT - 1024)
@@ -682,19 +820,19 @@ static int raise_lds(K kernel, const char *who) {
 
 extern "C" int64_t mappo_gru_scratch_floats(int32_t L, int32_t Nc) { return (int64_t)N_SCR * L * HID * Nc; }
 
-extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc, const float *xT, const float *h0,
+extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc, const float *xT, const float *giT, const float *h0,
                                  const int32_t *h0_rows, const float *masks, const int32_t *rows, int32_t L, int32_t Nc,
                                  float *h_last, float *scratch, int32_t head_mode, float *out, const float *avail,
                                  int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev,
                                  float *actions, float *logp, mappo_stream_t stream) {
   if (int rc = check_rec(desc, "gru_forward")) return rc;
-  MAPPO_REQUIRE(params && xT && h0 && masks && L > 0 && Nc > 0, "gru_forward: bad arguments");
+  MAPPO_REQUIRE(params && (xT || giT) && h0 && masks && L > 0 && Nc > 0, "gru_forward: bad arguments");
   MAPPO_REQUIRE(head_mode >= 0 && head_mode <= 2, "gru_forward: head_mode %d", head_mode);
   MAPPO_REQUIRE(head_mode != 1 || out, "gru_forward: out required");
   MAPPO_REQUIRE(head_mode != 2 || (actions && logp), "gru_forward: actions/logp required");
   MAPPO_CLEAR_STICKY();
   GruFwdArgs a = {};
-  a.params = params; a.off = net_offsets(*desc); a.xT = xT; a.h0 = h0; a.h0_rows = h0_rows; a.masks = masks; a.rows = rows;
+  a.params = params; a.off = net_offsets(*desc); a.xT = xT; a.giT = giT; a.h0 = h0; a.h0_rows = h0_rows; a.masks = masks; a.rows = rows;
   a.L = L; a.Nc = Nc; a.A = desc->out_dim; a.head_mode = head_mode; a.h_last = h_last; a.scratch = scratch; a.out = out;
   a.avail = avail; a.actions = actions; a.logp = logp; a.deterministic = deterministic; a.seed = seed; a.counter = counter;
   a.counter_dev = counter_dev;
@@ -702,7 +840,7 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   int nw = head_mode ? 2 : 4;
   while (nw > 1 && n_tiles < nw) nw >>= 1;
   const int wave_rows = head_mode ? (HID + HID + TS) : HID;
-  a.map = gru_lds(nw, wave_rows);
+  a.map = gru_lds(nw, wave_rows, giT == nullptr);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_forward: needs %zu B of LDS", lds_bytes);
   static bool attr = false;
@@ -726,8 +864,8 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
                                   const mappo_ppo_cfg *cfg, float *dxT, float *dgiT, float *dghnT, float *slabs,
                                   int64_t slab_stride, int64_t slab_col0, double *partials, mappo_stream_t stream) {
   if (int rc = check_rec(desc, "gru_backward")) return rc;
-  MAPPO_REQUIRE(params && scratch && masks && active && mb_moments && cfg && dxT && dgiT && dghnT && slabs && partials && L > 0 && Nc > 0,
-                "gru_backward: bad arguments");
+  MAPPO_REQUIRE(params && scratch && masks && active && mb_moments && cfg && dgiT && dghnT && slabs && partials && L > 0 && Nc > 0,
+                "gru_backward: bad arguments");              // dxT == NULL: d x deferred to mappo_gru_input_backward
   MAPPO_REQUIRE(head == 1 || head == 2, "gru_backward: head %d", head);
   MAPPO_REQUIRE(head != 1 || (actions && old_logp && adv), "gru_backward: actor loss inputs");
   MAPPO_REQUIRE(head != 2 || (v_old && returns && (!cfg->use_valuenorm || vn_state)), "gru_backward: critic loss inputs");
@@ -738,7 +876,7 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
   a.v_old = v_old; a.returns = returns; a.vn_state = vn_state; a.mb_moments = mb_moments; a.cfg = *cfg; a.dxT = dxT; a.dgiT = dgiT;
   a.dghnT = dghnT; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0; a.partials = partials;
   MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru_backward: slab column range");
-  a.map = gru_lds(1, NG + HID + TS);
+  a.map = gru_lds(1, NG + HID + TS, dxT != nullptr);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_backward: needs %zu B of LDS", lds_bytes);
   static bool attr = false;
@@ -771,4 +909,38 @@ extern "C" int mappo_gru_wgrad(const mappo_net_desc *desc, const float *xT, cons
   hipLaunchKernelGGL(gru_wgrad_kernel, dim3(nb), dim3(256), lds_bytes, as_stream(stream), a);
   MAPPO_CHECK_LAUNCH("gru_wgrad");
   return MAPPO_OK;
+}
+
+static int launch_gru_in(bool gates, const float *params, const mappo_net_desc *desc, const float *inT, int64_t B, float *outT,
+                         hipStream_t st, const char *who) {
+  if (int rc = check_rec(desc, who)) return rc;
+  MAPPO_REQUIRE(params && inT && outT && B > 0, "%s: bad arguments", who);
+  MAPPO_CLEAR_STICKY();
+  GruInArgs a = {};
+  a.params = params; a.off = net_offsets(*desc); a.inT = inT; a.outT = outT; a.B = B;
+  const size_t lds_bytes = (size_t)(al4(HID * GS) + NG) * sizeof(float);
+  const int64_t n_tiles = (B + TS - 1) / TS;
+  int64_t nb = (n_tiles + 3) / 4;
+  if (nb > NUM_CU) nb = NUM_CU;
+  if (gates) {
+    static bool attr = false;
+    if (!attr) { if (int rc = raise_lds(gru_gi_kernel, who)) return rc; attr = true; }
+    hipLaunchKernelGGL(gru_gi_kernel, dim3((unsigned)nb), dim3(256), lds_bytes, st, a);
+  } else {
+    static bool attr = false;
+    if (!attr) { if (int rc = raise_lds(gru_dx_kernel, who)) return rc; attr = true; }
+    hipLaunchKernelGGL(gru_dx_kernel, dim3((unsigned)nb), dim3(256), lds_bytes, st, a);
+  }
+  MAPPO_CHECK_LAUNCH(who);
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_gru_input_gates(const float *params, const mappo_net_desc *desc, const float *xT, int64_t B, float *giT,
+                                     mappo_stream_t stream) {
+  return launch_gru_in(true, params, desc, xT, B, giT, as_stream(stream), "gru_input_gates");
+}
+
+extern "C" int mappo_gru_input_backward(const float *params, const mappo_net_desc *desc, const float *dgiT, int64_t B, float *dxT,
+                                        mappo_stream_t stream) {
+  return launch_gru_in(false, params, desc, dgiT, B, dxT, as_stream(stream), "gru_input_backward");
 }

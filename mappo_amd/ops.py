@@ -287,9 +287,22 @@ def gru_scratch_floats(L, Nc):
     return int(_lib.load().mappo_gru_scratch_floats(int(L), int(Nc)))
 
 
+def gru_input_gates(params, desc, featT, B, giT):
+    """giT [192][B] = W_ih featT + b_ih for all rows at once (training: outside the sequential kernel)."""
+    rc = _lib.load().mappo_gru_input_gates(_ptr(params), C.byref(desc), _ptr(featT), int(B), _ptr(giT), _stream())
+    _lib.check(rc, "mappo_gru_input_gates")
+
+
+def gru_input_backward(params, desc, dgiT, B, dxT):
+    """dxT [64][B] = W_ih^T dgiT for all rows at once."""
+    rc = _lib.load().mappo_gru_input_backward(_ptr(params), C.byref(desc), _ptr(dgiT), int(B), _ptr(dxT), _stream())
+    _lib.check(rc, "mappo_gru_input_backward")
+
+
 def gru_forward(params, desc, featT, h0, h0_rows, masks, rows, L, Nc, h_last=None, scratch=None, head_mode=0, out=None,
-                avail=None, deterministic=False, seed=0, counter=0, counter_dev=None, actions=None, logp=None):
-    rc = _lib.load().mappo_gru_forward(_ptr(params), C.byref(desc), _ptr(featT), _ptr(h0), _ptr(h0_rows, torch.int32, allow_none=True),
+                avail=None, deterministic=False, seed=0, counter=0, counter_dev=None, actions=None, logp=None, giT=None):
+    rc = _lib.load().mappo_gru_forward(_ptr(params), C.byref(desc), _ptr(featT), _ptr(giT, allow_none=True), _ptr(h0),
+                                       _ptr(h0_rows, torch.int32, allow_none=True),
                                        _ptr(masks), _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc),
                                        _ptr(h_last, allow_none=True), _ptr(scratch, allow_none=True), int(head_mode),
                                        _ptr(out, allow_none=True), _ptr(avail, allow_none=True), int(bool(deterministic)),
@@ -308,7 +321,7 @@ def gru_backward(params, desc, scratch, masks, rows, L, Nc, head, avail, actions
     n = lambda t: _ptr(t, allow_none=True)
     rc = _lib.load().mappo_gru_backward(_ptr(params), C.byref(desc), _ptr(scratch), _ptr(masks), _ptr(rows, torch.int32, allow_none=True),
                                         int(L), int(Nc), int(head), n(avail), n(actions), n(old_logp), n(adv), _ptr(active), n(v_old),
-                                        n(returns), n(vn_state), _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(dxT), _ptr(dgiT),
+                                        n(returns), n(vn_state), _ptr(mb_moments, torch.float64), C.byref(cfg), n(dxT), _ptr(dgiT),
                                         _ptr(dghnT), _ptr(slabs), int(slab_stride), int(slab_col0), _ptr(partials, torch.float64),
                                         _stream())
     _lib.check(rc, "mappo_gru_backward")

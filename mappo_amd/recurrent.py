@@ -31,7 +31,7 @@ class _Scratch:
             f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
             s = dict(featT=f(H, B))
             if training:
-                s.update(gates=f(ops.gru_scratch_floats(L, Nc)), dxT=f(H, B), dgiT=f(3 * H, B), dghnT=f(H, B))
+                s.update(gates=f(ops.gru_scratch_floats(L, Nc)), dxT=f(H, B), dgiT=f(3 * H, B), dghnT=f(H, B), giT=f(3 * H, B))
             self._c[key] = s
         return s
 
@@ -119,12 +119,17 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
     def one_net(net, x, h0, head, part, col0, tag):
         s = _scratch.get(dev, L, Nc, True, tag)
         ops.mlp_features(net.flat, net.desc, x, rows, B, s["featT"])
-        ops.gru_forward(net.flat, net.desc, s["featT"], h0, h0_rows, src["masks"], rows, L, Nc, scratch=s["gates"], head_mode=0)
+        # input-side products (W_ih x, W_ih^T dgi) run as plain row-tile kernels over all rows; the sequential kernels carry
+        # only the W_hh half and, without W_ih in LDS, two of their workgroups (actor's and critic's) share a CU
+        ops.gru_input_gates(net.flat, net.desc, s["featT"], B, s["giT"])
+        ops.gru_forward(net.flat, net.desc, s["featT"], h0, h0_rows, src["masks"], rows, L, Nc, scratch=s["gates"], head_mode=0,
+                        giT=s["giT"])
         ops.gru_backward(net.flat, net.desc, s["gates"], src["masks"], rows, L, Nc, head,
                          src["avail"] if head == 1 else None, src["actions"] if head == 1 else None,
                          src["old_logp"] if head == 1 else None, src["adv"] if head == 1 else None, src["active"],
                          src["v_old"] if head == 2 else None, src["returns"] if head == 2 else None,
-                         vn_state if head == 2 else None, tr._mb_moments, tr._cfg, s["dxT"], s["dgiT"], s["dghnT"], slabs, P, col0, part)
+                         vn_state if head == 2 else None, tr._mb_moments, tr._cfg, None, s["dgiT"], s["dghnT"], slabs, P, col0, part)
+        ops.gru_input_backward(net.flat, net.desc, s["dgiT"], B, s["dxT"])
         ops.gru_wgrad(net.desc, s["featT"], s["gates"], s["dgiT"], s["dghnT"], L, Nc, slabs, P, col0)
         ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
 
