@@ -121,6 +121,18 @@ class R_MAPPO():
             ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper,
                           pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=self._acc[4:])
 
+    def _moments(self, src, rows, B, vn_state):
+        """{sum ret, sum ret^2, sum active, B} of the minibatch (+ the data-parallel all-reduce) and, in the epoch-batched
+        mode, all ppo_epoch ValueNorm updates in one launch (every epoch sees the same batch moments)."""
+        lib = ops._lib.load()
+        ops.minibatch_moments(src["returns"], src["active"], rows, B, self._mb_moments,
+                              self._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
+        if self._dist is not None:
+            self._dist.all_reduce_sum_(self._mb_moments)
+        ep = self._epochs
+        if ep is not None and self._use_valuenorm:
+            ops.valuenorm_update_n(vn_state, self._mb_moments, self.value_normalizer.beta, ep["n"], ep["states"])
+
     def _update_kernels(self, src, rows, B, update_actor, moments_ready, vn_state, n_slabs, P):
         pol = self.policy
         A = pol.actor.n_actions
@@ -129,13 +141,7 @@ class R_MAPPO():
         # `moments_ready`: the minibatch is the whole buffer again, its sums were taken by the first epoch
         ep = self._epochs
         if not moments_ready:
-            ops.minibatch_moments(src["returns"], src["active"], rows, B, self._mb_moments,
-                                  self._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
-            if self._dist is not None:
-                self._dist.all_reduce_sum_(self._mb_moments)
-            if ep is not None and self._use_valuenorm:
-                # every epoch sees the same batch moments: all ppo_epoch ValueNorm updates in one launch
-                ops.valuenorm_update_n(vn_state, self._mb_moments, self.value_normalizer.beta, ep["n"], ep["states"])
+            self._moments(src, rows, B, vn_state)
         # (ValueNorm.update and the loss statistics are tiny kernels that nothing waits for immediately; forking them to a
         # side stream next to the update kernels measured SLOWER inside the captured hipGraph — train 1.96 ms vs 1.69 ms
         # at config 2 — so the chain stays on one stream.)
@@ -187,8 +193,7 @@ class R_MAPPO():
                 n_pa = n_pc = n_slabs
             if ep is None:
                 ops.update_stats(pa if update_actor else None, n_pa, pc, n_pc, self._mb_moments, self._cfg, self._stats, self._acc)
-            else:
-                ep["stats_args"] = (pa if update_actor else None, n_pa, pc, n_pc)
+
         else:
             # evaluate_actions: logits and values (rMAPPOPolicy.py:88-114)
             logits = self._buf("logits", (B, A))
@@ -279,10 +284,16 @@ class R_MAPPO():
         dp_graph = self._dist is not None and self._use_graph and whole and self._fused and self._dist.world_is_gpu
         key = (id(buffer), bool(update_actor))
         self._epochs = None
-        if whole and self._fused and self._dist is None and not self._concurrent_update and os.environ.get("MAPPO_EPOCH_BATCH", "1") != "0":
+        if whole and self._fused and (self._dist is None or dp_graph) and not self._concurrent_update \
+                and os.environ.get("MAPPO_EPOCH_BATCH", "1") != "0":
             # every update sees the same minibatch (the whole buffer): ValueNorm's ppo_epoch updates are one launch, the
             # loss sums accumulate in the kernels' partials and the statistics kernel runs once after the last epoch
-            self._epochs = dict(n=self.ppo_epoch, e=0, states=self._buf("vn_states", (self.ppo_epoch, 3)), stats_args=None)
+            self._epochs = dict(n=self.ppo_epoch, e=0, states=self._buf("vn_states", (self.ppo_epoch, 3)))
+        if dp_graph:
+            # data parallel: the moments (one 4-double all-reduce) come first, so that EVERY epoch is the same collective-free
+            # kernel segment (captured per epoch: the ValueNorm state an epoch reads sits at its own address)
+            vn_state = self.value_normalizer.state if self._use_valuenorm else None
+            self._moments(src, None, S, vn_state)
         for epoch in range(self.ppo_epoch):
             if self._epochs is not None:
                 self._epochs["e"] = epoch
@@ -291,21 +302,24 @@ class R_MAPPO():
             else:
                 batches = [(rows, rows.numel()) for rows in buffer.feed_forward_rows(self.num_mini_batch)]
             for rows, B in batches:
-                if dp_graph and epoch > 0:
+                if dp_graph:
                     # data parallel: the collective stays outside; the kernels between two collectives are one hipGraph
-                    st = self._dp_graphs.get(key)
+                    gkey = key + (epoch,)
+                    st = self._dp_graphs.get(gkey)
+                    if st is None and self._dp_graphs.get(key) == "warm":
+                        st = "warm"
                     if st == "warm":
                         torch.cuda.synchronize()
                         try:
                             g = torch.cuda.CUDAGraph()
                             with torch.cuda.graph(g, capture_error_mode="thread_local"):     # RCCL's watchdog thread stays legal
                                 self._update(src, rows, B, update_actor, moments_ready=True, part="kernels")
-                            self._dp_graphs[key] = st = g
+                            self._dp_graphs[gkey] = st = g
                         except Exception as e:                      # never let a failed capture take a multi-GPU run down
                             import warnings
                             warnings.warn(f"hipGraph capture of the data-parallel update segment failed ({e}); launching eagerly")
                             torch.cuda.synchronize()
-                            self._dp_graphs[key] = st = "off"
+                            self._dp_graphs[gkey] = st = "off"
                     if st == "off":
                         st = None
                     if st is None:
@@ -316,7 +330,12 @@ class R_MAPPO():
                 else:
                     self._update(src, rows, B, update_actor, moments_ready=whole and epoch > 0)
         if self._epochs is not None:
-            ops.update_stats(*self._epochs["stats_args"], self._mb_moments, self._cfg, self._stats, self._acc)
+            # (rows of loss partials the update kernels wrote; not taken from a side effect of _update_kernels: under data
+            # parallelism the epochs may have been graph replays, during which no Python runs)
+            n_rows = ops.dual_update_slabs(S) if (update_actor and self._dual_update and self.policy.can_fuse_step()) \
+                else ops.mlp_backward_slabs(S)
+            ops.update_stats(self._pa if update_actor else None, n_rows, self._pc, n_rows, self._mb_moments, self._cfg, self._stats,
+                             self._acc)
             self._epochs = None
         if dp_graph and self._dp_graphs.get(key) is None:
             self._dp_graphs[key] = "warm"                      # first train() ran eagerly: workspaces exist now

@@ -44,70 +44,6 @@ __global__ __launch_bounds__(SLAB_BLOCK) void slab_reduce_kernel(const float *__
   grad[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
-__global__ __launch_bounds__(OPT_BLOCK) void sqnorm_partial_kernel(const float *__restrict__ grad, int64_t P,
-                                                                  double *__restrict__ partials) {
-  __shared__ double smem[16];
-  const int64_t p = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x;
-  double v[1] = {0.0};
-  if (p < P) { const double g = (double)grad[p]; v[0] = g * g; }
-  block_sum<1>(v, smem);
-  if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
-}
-
-// One block: per-segment norm, clip coefficient, step increment, bias corrections.
-// seg_ws[s*4 + {0,1,2,3}] = {clip coef, step_size = lr/(1-b1^t), sqrt(1-b2^t), enabled}
-__global__ __launch_bounds__(OPT_BLOCK) void norm_finalize_kernel(const double *__restrict__ partials, SegBounds sb,
-                                                                 const float *__restrict__ hyper, int32_t *step,
-                                                                 float *__restrict__ grad_norms, float *__restrict__ seg_ws,
-                                                                 double *__restrict__ norm_acc) {
-  __shared__ double smem[16];
-  for (int s = 0; s < sb.n; ++s) {
-    const int b0 = (int)(sb.b[s] / OPT_BLOCK), b1 = (int)(sb.b[s + 1] / OPT_BLOCK);
-    double v[1] = {0.0};
-    for (int b = b0 + threadIdx.x; b < b1; b += blockDim.x) v[0] += partials[b];
-    block_sum<1>(v, smem);
-    if (threadIdx.x == 0) {
-      const float *h = hyper + s * 8;
-      const float norm = (float)sqrt(v[0]);
-      const bool enabled = h[7] != 0.f;
-      float coef = 1.f;
-      if (h[6] != 0.f) coef = fminf(h[5] / (norm + 1e-6f), 1.f);
-      int t = step[s];
-      if (enabled) { t += 1; step[s] = t; }
-      const double bc1 = 1.0 - pow((double)h[1], (double)t);
-      const double bc2 = 1.0 - pow((double)h[2], (double)t);
-      grad_norms[s] = norm;
-      if (norm_acc) norm_acc[s] += (double)norm;      // train_info's running sum of the pre-clip norms
-      seg_ws[s * 4 + 0] = coef;
-      seg_ws[s * 4 + 1] = (float)((double)h[0] / (bc1 > 0.0 ? bc1 : 1.0));
-      seg_ws[s * 4 + 2] = (float)sqrt(bc2 > 0.0 ? bc2 : 1.0);
-      seg_ws[s * 4 + 3] = enabled ? 1.f : 0.f;
-    }
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(OPT_BLOCK) void adam_kernel(float *__restrict__ params, const float *__restrict__ grad,
-                                                        float *__restrict__ m, float *__restrict__ v, SegBounds sb,
-                                                        const float *__restrict__ hyper, const float *__restrict__ seg_ws) {
-  const int64_t i = (int64_t)blockIdx.x * OPT_BLOCK + threadIdx.x;
-  if (i >= sb.b[sb.n]) return;
-  const int s = seg_of(sb, (int64_t)blockIdx.x * OPT_BLOCK);
-  const float *h = hyper + s * 8;
-  const float *w = seg_ws + s * 4;
-  if (w[3] == 0.f) return;
-  const float b1 = h[1], b2 = h[2], eps = h[3], wd = h[4];
-  float g = grad[i] * w[0];
-  float p = params[i];
-  if (wd != 0.f) g = g + wd * p;
-  float mi = m[i], vi = v[i];
-  mi = mi + (g - mi) * (1.f - b1);
-  vi = vi * b2 + g * g * (1.f - b2);
-  const float denom = sqrtf(vi) / w[2] + eps;
-  p = p - w[1] * (mi / denom);
-  params[i] = p; m[i] = mi; v[i] = vi;
-}
-
 // ---- two-launch variant of slab_reduce + clip_adam (the per-update tail of the PPO loop is launch-bound: every
 // kernel here runs a few microseconds, so the launches themselves are what it costs) --------------------------------
 // (1) slab_reduce that also leaves the squared-norm partial of its 128 gradient entries;
@@ -134,6 +70,19 @@ __global__ __launch_bounds__(SLAB_BLOCK) void slab_reduce_sq_kernel(const float 
     grad[p] = g;
   }
   double v[1] = {(double)g * (double)g};
+  block_sum<1>(v, smem);
+  if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
+}
+
+// squared-norm partials per 128 gradient entries (+ the Adam step increment of the enabled segments): the first launch of
+// mappo_clip_adam when the gradient was reduced elsewhere (data-parallel all-reduce, recurrent path)
+__global__ __launch_bounds__(SLAB_BLOCK) void sqnorm128_kernel(const float *__restrict__ grad, int64_t P, double *__restrict__ partials,
+                                                              const float *__restrict__ hyper, int32_t *step, int n_seg) {
+  __shared__ double smem[16];
+  if (blockIdx.x == 0 && threadIdx.x < n_seg && hyper[threadIdx.x * 8 + 7] != 0.f) step[threadIdx.x] += 1;
+  const int64_t p = (int64_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
+  double v[1] = {0.0};
+  if (p < P) { const double g = (double)grad[p]; v[0] = g * g; }
   block_sum<1>(v, smem);
   if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
 }
@@ -224,16 +173,14 @@ extern "C" int mappo_clip_adam(float *params, const float *grad, float *exp_avg,
   }
   MAPPO_REQUIRE(seg_bounds[0] == 0, "clip_adam: seg_bounds[0] must be 0");
   const int64_t P = seg_bounds[n_seg];
-  const int nblk = (int)(P / OPT_BLOCK);
   double *partials = (double *)workspace;
-  float *seg_ws = (float *)((char *)workspace + (((size_t)nblk * sizeof(double) + 63) / 64) * 64);
   hipStream_t st = as_stream(stream);
+  // two launches: squared-norm partials (+ step increment), then norm finalisation + Adam in one kernel
   PROF_BEGIN(MAPPO_PROF_ADAM, st);
-  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, grad, P, partials);
-  hipLaunchKernelGGL(norm_finalize_kernel, dim3(1), dim3(OPT_BLOCK), 0, st, (const double *)partials, sb, opt_hyper,
-                     opt_step, grad_norms, seg_ws, norm_acc);
-  hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(OPT_BLOCK), 0, st, params, grad, exp_avg, exp_avg_sq, sb, opt_hyper,
-                     (const float *)seg_ws);
+  hipLaunchKernelGGL(sqnorm128_kernel, dim3((unsigned)(P / SLAB_BLOCK)), dim3(SLAB_BLOCK), 0, st, grad, P, partials, opt_hyper, opt_step,
+                     (int)n_seg);
+  hipLaunchKernelGGL(norm_adam_kernel, dim3((unsigned)(P / OPT_BLOCK)), dim3(OPT_BLOCK), 0, st, (const double *)partials, sb, opt_hyper,
+                     (const int32_t *)opt_step, grad_norms, norm_acc, params, grad, exp_avg, exp_avg_sq);
   PROF_END(MAPPO_PROF_ADAM, st);
   MAPPO_CHECK_LAUNCH("clip_adam");
   return MAPPO_OK;
