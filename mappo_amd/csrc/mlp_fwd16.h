@@ -95,21 +95,23 @@ __device__ __forceinline__ void forward16_body(const FwdArgs &p, float *lds, con
 #pragma unroll
     for (int g = 0; g < 16; ++g) xin[g] = (ok && 4 * g + q < D) ? xin[g] : 0.f;
     if (fnorm) {
+      // slots with 4 g + q >= D hold 0: they add (0 - mean)^2 to the centred sum (taken out again below), and their
+      // gamma / beta entries are staged as 0, so no lane predicate is needed after the zeroing above
       float s = 0.f;
 #pragma unroll
       for (int g = 0; g < 16; ++g) s += xin[g];
       const float mean = quad_sum16(s) * inv_D;
       float v = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) { const float c = (4 * g + q < D) ? xin[g] - mean : 0.f; v += c * c; }
-      const float rstd = 1.0f / sqrtf(quad_sum16(v) * inv_D + LN_EPS);
+      for (int g = 0; g < 16; ++g) { const float c = xin[g] - mean; v += c * c; }
+      const int n_empty = 16 - max(0, min(16, (D - q + 3) >> 2));            // slots of this lane beyond D
+      v -= (float)n_empty * mean * mean;
+      const float rstd = 1.0f / sqrtf(fmaxf(quad_sum16(v), 0.f) * inv_D + LN_EPS);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
-        const int k = min(4 * g + q, D - 1);
-        xin[g] = (4 * g + q < D) ? (xin[g] - mean) * rstd * lds[m.fn_w + k] + lds[m.fn_b + k] : 0.f;
-      }
+      for (int g = 0; g < 16; ++g) xin[g] = (xin[g] - mean) * rstd * lds[m.fn_w + 4 * g + q] + lds[m.fn_b + 4 * g + q];
     }
-    // ---- layer 1: k-group g = input features 4 g + q ----
+    // ---- layer 1: k-group g = input features 4 g + q; groups come in chunks of four (one wave-uniform branch per chunk;
+    // a chunk's surplus groups multiply zeros: xin = 0 beyond D, weight row clamped) ----
     f32x4 h[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -117,11 +119,15 @@ __device__ __forceinline__ void forward16_body(const FwdArgs &p, float *lds, con
       h[b][0] = bv.x; h[b][1] = bv.y; h[b][2] = bv.z; h[b][3] = bv.w;
     }
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      if (g < NG) {                                                             // wave-uniform
-        const float *rowp = lds + m.w1 + min(4 * g + q, Dp - 1) * WP + j;      // rows >= D carry xin = 0
+    for (int c = 0; c < 4; ++c) {
+      if (4 * c < NG) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b) h[b] = mfma16(rowp[16 * b], xin[g], h[b]);
+        for (int gg = 0; gg < 4; ++gg) {
+          const int g = 4 * c + gg;
+          const float *rowp = lds + m.w1 + min(4 * g + q, Dp - 1) * WP + j;
+#pragma unroll
+          for (int b = 0; b < 4; ++b) h[b] = mfma16(rowp[16 * b], xin[g], h[b]);
+        }
       }
     }
     act_ln16<RELU>(h, lds + m.ln1_w, lds + m.ln1_b, q);
