@@ -480,6 +480,22 @@ __device__ __forceinline__ void update2_body(const UpdArgs &p, float *lds, doubl
             const int s = e / A, a = e - s * A;
             tZ[s * TP + a] = (s < n_valid) ? p.dout[base * A + e] : 0.f;
           }
+        } else if (HEAD == 2) {
+          // critic (out_dim 1): the head is one 64-term dot product per sample — on the VALU (each half sums 32 features),
+          // not a 32-step MFMA chain for one useful output row
+          const float *sW = lds + m.wh;
+          float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+          for (int f = 0; f < 32; f += 2) {
+            a0 += sW[(32 * half + f) * HP] * tLast[(32 * half + f) * TP + l31];
+            a1 += sW[(32 * half + f + 1) * HP] * tLast[(32 * half + f + 1) * TP + l31];
+          }
+          const float v = xhalf_sum(a0 + a1) + lds[m.bh];
+          if (lane < TS) {
+            float dvv = 0.f;
+            if (lane < n_valid) dvv = critic_loss_lane(v, cur.f0, cur.f1, cur.f2, p.cfg, ls, lacc);
+            tZ[lane * TP] = dvv;
+          }
         } else {
           const f32x16 z = head_forward1(lds, m, tLast, l31, half);
           if (HEAD == 1) {
@@ -510,7 +526,25 @@ __device__ __forceinline__ void update2_body(const UpdArgs &p, float *lds, doubl
     f32x16 dH;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dH[r] = 0.f;
-    if (HEAD != 3) {
+    if (HEAD == 2) {
+      // out_dim 1 on the VALU: G[f] = sum_s dv[s] xhat[f][s] (lane = feature row0 + l31, each half 16 samples),
+      // db = sum_s dv[s], d h[f][s] = Wh'[f] dv[s]
+      const float *rp = tLast + (row0 + l31) * TP + 16 * half;
+      float g0 = 0.f, g1 = 0.f, b0 = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 16; jj += 2) {
+        const float d0 = tZ[(16 * half + jj) * TP], d1 = tZ[(16 * half + jj + 1) * TP];
+        g0 += d0 * rp[jj]; g1 += d1 * rp[jj + 1];
+        b0 += d0 + d1;
+      }
+      const float gsum = xhalf_sum(g0 + g1), bsum = xhalf_sum(b0);
+      if (half == 0) gWh[0][0] += gsum;                  // accumulator element (a = 0, f = row0 + l31): lane (l31, half 0), register 0
+      if (fh == 0) gBh += bsum;
+      const float dvs = tZ[l31 * TP];
+      const float *sW = lds + m.wh;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dH[r] = sW[(row0 + ROWMAP(r, half)) * HP] * dvs;
+    } else if (HEAD != 3) {
       float bsum = 0.f;
 #pragma unroll 2
       for (int ss = 0; ss < TS / 2; ++ss) {
