@@ -124,54 +124,65 @@ __device__ __forceinline__ LossScales loss_scales(const mappo_ppo_cfg &cfg, cons
   return ls;
 }
 
+// Register form of the actor loss for A <= 8 (Discrete spaces of up to 8 actions — MPE's 5): z[0..A) logits in, the
+// gradient d(actor objective)/d logits out in g; fully unrolled, same expressions and evaluation order as the general
+// path of actor_loss_lane.  lacc[0..2] += w*min(s1,s2), w*H, ratio.
+__device__ __forceinline__ void actor_loss_regs(float (&z)[8], float (&g)[8], int A, uint32_t dead, int act, float old_lp, float adv,
+                                                float active, const mappo_ppo_cfg &cfg, float scale_pi, double (&lacc)[4]) {
+  const float clip8 = cfg.clip_param;
+  float e[8];
+  float zmax8 = -FLT_MAX;
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+    if (a < A) {
+      if (dead & (1u << a)) z[a] = -1e10f;
+      zmax8 = fmaxf(zmax8, z[a]);
+    }
+  float se8 = 0.f;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) { e[a] = 0.f; if (a < A) { e[a] = expf(z[a] - zmax8); se8 += e[a]; } }
+  const float log_se8 = logf(se8), inv_se8 = 1.0f / se8;
+  float H8 = 0.f, z_act = z[0];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+    if (a < A) {
+      const float l_ = (z[a] - zmax8) - log_se8;
+      H8 -= (e[a] * inv_se8) * fmaxf(l_, -FLT_MAX);
+      if (a == act) z_act = z[a];
+    }
+  const float logp8 = (z_act - zmax8) - log_se8;
+  const float ratio8 = expf(logp8 - old_lp);
+  const float s18 = ratio8 * adv, s28 = fminf(fmaxf(ratio8, 1.f - clip8), 1.f + clip8) * adv;
+  const float w8 = cfg.use_policy_active_masks ? active : 1.f;
+  const float dlogp8 = (s18 <= s28) ? -(w8 * scale_pi) * adv * ratio8 : 0.f;
+  const float ce8 = cfg.entropy_coef * w8 * scale_pi;
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    g[a] = 0.f;
+    if (a < A) {
+      const float l_ = (z[a] - zmax8) - log_se8;
+      const float pa = e[a] * inv_se8;
+      float gg = dlogp8 * ((a == act ? 1.f : 0.f) - pa) + ce8 * pa * (l_ + H8);
+      if (dead & (1u << a)) gg = 0.f;
+      g[a] = gg;
+    }
+  }
+  lacc[0] += (double)(w8 * fminf(s18, s28));
+  lacc[1] += (double)(w8 * H8);
+  lacc[2] += (double)ratio8;
+}
+
 // zl[0..A): logits of this sample (row of a [s][TP] LDS tile, columns 16..31 free when A <= 16); on return zl holds
 // d(actor objective)/d logits.  lacc[0..2] += w*min(s1,s2), w*H, ratio.
 __device__ __forceinline__ void actor_loss_lane(float *zl, int A, uint32_t dead, int act, float old_lp, float adv, float active,
                                                 const mappo_ppo_cfg &cfg, float scale_pi, double (&lacc)[4]) {
   if (A <= 8) {
-    // register path (Discrete spaces of up to 8 actions — MPE's 5): the logits are read once, everything else happens
-    // in registers with fully unrolled loops; same expressions and evaluation order as the general path below
-    const float clip8 = cfg.clip_param;
-    float z[8], e[8];
+    float z[8], g[8];
 #pragma unroll
     for (int a = 0; a < 8; ++a) z[a] = zl[a < A ? a : 0];
-    float zmax8 = -FLT_MAX;
+    actor_loss_regs(z, g, A, dead, act, old_lp, adv, active, cfg, scale_pi, lacc);
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
-      if (a < A) {
-        if (dead & (1u << a)) z[a] = -1e10f;
-        zmax8 = fmaxf(zmax8, z[a]);
-      }
-    float se8 = 0.f;
-#pragma unroll
-    for (int a = 0; a < 8; ++a) { e[a] = 0.f; if (a < A) { e[a] = expf(z[a] - zmax8); se8 += e[a]; } }
-    const float log_se8 = logf(se8), inv_se8 = 1.0f / se8;
-    float H8 = 0.f, z_act = z[0];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-      if (a < A) {
-        const float l_ = (z[a] - zmax8) - log_se8;
-        H8 -= (e[a] * inv_se8) * fmaxf(l_, -FLT_MAX);
-        if (a == act) z_act = z[a];
-      }
-    const float logp8 = (z_act - zmax8) - log_se8;
-    const float ratio8 = expf(logp8 - old_lp);
-    const float s18 = ratio8 * adv, s28 = fminf(fmaxf(ratio8, 1.f - clip8), 1.f + clip8) * adv;
-    const float w8 = cfg.use_policy_active_masks ? active : 1.f;
-    const float dlogp8 = (s18 <= s28) ? -(w8 * scale_pi) * adv * ratio8 : 0.f;
-    const float ce8 = cfg.entropy_coef * w8 * scale_pi;
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-      if (a < A) {
-        const float l_ = (z[a] - zmax8) - log_se8;
-        const float pa = e[a] * inv_se8;
-        float g = dlogp8 * ((a == act ? 1.f : 0.f) - pa) + ce8 * pa * (l_ + H8);
-        if (dead & (1u << a)) g = 0.f;
-        zl[a] = g;
-      }
-    lacc[0] += (double)(w8 * fminf(s18, s28));
-    lacc[1] += (double)(w8 * H8);
-    lacc[2] += (double)ratio8;
+    for (int a = 0; a < 8; ++a) if (a < A) zl[a] = g[a];
     return;
   }
   const float clip = cfg.clip_param;
