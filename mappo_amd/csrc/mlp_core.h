@@ -286,9 +286,10 @@ __device__ __forceinline__ void categorical_act_lane(float *zl, int A, const flo
 
 // head output (accumulator layout) -> tZ[s][a]
 __device__ __forceinline__ void head_to_tile(float *tZ, const f32x16 &z, int A, int l31, int half) {
+  // rows a >= A go to column 32 of the row (the tile's padding column): an address select instead of 16 exec-mask regions
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int a = ROWMAP(r, half);
-    if (a < A) tZ[l31 * TP + a] = z[r];
+    tZ[l31 * TP + (a < A ? a : TP - 1)] = z[r];
   }
 }

@@ -141,6 +141,8 @@ __device__ __forceinline__ void commit_half(float *tX, float *tF, float *dummy, 
 // never fed to an MFMA.
 __device__ __forceinline__ void mfma_chain_p(f32x16 &acc, int n, const float *pa, int sa, const float *pb, int sb) {
 #if !defined(EXP_MFMA_NOPIPE)
+  // (a second, interleaved accumulator — a dependent MFMA waits ~100 cycles for its predecessor — measured -2 % on the
+  // critic kernel but cost the register-tighter actor kernel spills; with the two in one launch the actor is the bound)
   float a[6], b[6];
   a[0] = pa[0]; b[0] = pb[0]; a[1] = pa[sa]; b[1] = pb[sb];
   for (int k0 = 0; k0 < n; k0 += 4) {
@@ -498,9 +500,11 @@ __device__ __forceinline__ void update2_body(const UpdArgs &p, float *lds, doubl
           }
         } else {
           const f32x16 z = head_forward1(lds, m, tLast, l31, half);
+          STAMP(18);  // head forward (MFMA chain)
           if (HEAD == 1) {
             head_to_tile(tZ, z, A, l31, half);
             wave_lds_sync();
+            STAMP(19);  // logits -> tile
             if (lane < TS) {
               float *zl = tZ + lane * TP;
               if (lane < n_valid) {
@@ -509,6 +513,7 @@ __device__ __forceinline__ void update2_body(const UpdArgs &p, float *lds, doubl
                 for (int a = 0; a < A; ++a) zl[a] = 0.f;
               }
             }
+            STAMP(20);  // per-sample loss
           } else {
             if (lane < TS) {
               float dvv = 0.f;

@@ -14,7 +14,7 @@ _lib.SIGNATURES['mappo_debug_set_stamps'] = (ctypes.c_int, [ctypes.c_void_p])
 from mappo_amd import ops
 lib = _lib.load()
 NAMES = ['staging', 'sync after commit', 'trunk fwd', 'head fwd + loss', 'head grads A,B', 'LNbwd hidden', 'dW2', 'dH hidden',
-         'LNbwd L1', 'dW1', 'dX + fn grads', 'loop exit + raw->grad', 'block reduce (LDS)', 'slab write', '(of which: pair_sync)', '', 'commit_half', 'prefetch issue', '', '', '', '', '', '']
+         'LNbwd L1', 'dW1', 'dX + fn grads', 'loop exit + raw->grad', 'block reduce (LDS)', 'slab write', '(of which: pair_sync)', '', 'commit_half', 'prefetch issue', 'head fwd MFMA', 'logits->tile', 'loss lanes', '', '', '']
 class A_: pass
 a = A_(); a.clip_param=0.2; a.entropy_coef=0.01; a.value_loss_coef=1.0; a.huber_delta=10.0; a.use_huber_loss=True; a.use_clipped_value_loss=True; a.use_policy_active_masks=True; a.use_value_active_masks=True; a.use_valuenorm=True
 cfg = ops.ppo_cfg(a)
