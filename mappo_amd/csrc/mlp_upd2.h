@@ -39,7 +39,11 @@ __device__ __forceinline__ void pair_sync(PairSync &ps, int lane) {
 #endif
   ps.epoch += 2u;
   if (lane == 0) (void)__hip_atomic_fetch_add(ps.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  while (__hip_atomic_load(ps.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ps.epoch) { }
+  while (__hip_atomic_load(ps.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < ps.epoch) {
+#ifdef EXP_SYNC_SLEEP
+    __builtin_amdgcn_s_sleep(EXP_SYNC_SLEEP);
+#endif
+  }
 #ifdef MLP_STAMPS
   ps.cyc += __builtin_readcyclecounter() - t0_;
 #endif
