@@ -381,3 +381,36 @@ def test_concurrent_update_launch_matches_sequential(M):
         close(res[0][0][k], res[1][0][k], 1e-5, 1e-7, k)
     close(res[0][2], res[1][2], 1e-4, 1e-7, "last gradient")
     close(res[0][1], res[1][1], 1e-5, 2e-6, "parameters")
+
+
+def test_data_parallel_path_matches_single_process(M):
+    """The data-parallel trainer (moments first, per-epoch captured kernel segments, eager all-reduce + clip_adam, rollout
+    graph with thread-local capture) on ONE rank with a real NCCL/RCCL process group must reproduce the single-process
+    run: same weights after several iterations (the all-reduce over one rank is the identity), replays included."""
+    import torch.distributed as dist
+    from mappo_amd.distributed import DataParallel
+    T, N, Ma, D, A = 25, 64, 3, 18, 5
+
+    def run(dp):
+        a = make_args(M, episode_length=T, n_rollout_threads=N, ppo_epoch=4, lr=7e-4, critic_lr=7e-4, seed=1, env_name="MPE")
+        torch.manual_seed(1)
+        env = M.SyntheticMPEEnv(N, Ma, D, A, T, seed=1)
+        r = M.MPERunner(dict(all_args=a, envs=env, eval_envs=None, num_agents=Ma, device=torch.device("cuda"), run_dir=None, dist_group=dp))
+        r.warmup()
+        infos = [r.run_episode(i, 5)[0] for i in range(4)]           # eager, capture, replay, replay
+        torch.cuda.synchronize()
+        return infos, r.trainer.policy.flat_params.clone()
+
+    infos0, p0 = run(None)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        infos1, p1 = run(DataParallel())
+    finally:
+        if created:
+            dist.destroy_process_group()
+    for i0, i1 in zip(infos0, infos1):
+        for k in i0:
+            np.testing.assert_allclose(i1[k], i0[k], rtol=2e-5, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(p1.cpu().numpy(), p0.cpu().numpy(), rtol=0, atol=2e-6)
