@@ -294,12 +294,16 @@ struct GruFwdArgs {
   const uint64_t *counter_dev;
 };
 
+// PRE_GI: input gates precomputed (training); HM: head mode 0 none | 1 out[B][A] | 2 sample.  Compile-time so that each use
+// (rollout step with sampling, evaluation with head output, training with scratch stores) is a lean instantiation — as one
+// kernel with runtime switches the register allocator spilled ~200 registers.
+template <bool PRE_GI, int HM>
 __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
   extern __shared__ __align__(16) float lds[];
   const GruLds &m = p.map;
   const int n_waves = blockDim.x / WAVE;
   const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
-  stage_gru_all(lds, m, p.params, p.off, p.A, p.giT == nullptr, p.head_mode != 0);
+  stage_gru_all(lds, m, p.params, p.off, p.A, !PRE_GI, HM != 0);
   __syncthreads();
   float *tHm = lds + m.tiles + wave * m.wave_stride;     // [64][TP] masked previous state (B operand)
   float *tN = tHm + HID * TP;                            // [64][TP] normalised state (head input)   (head modes only)
@@ -324,8 +328,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
       regs_to_tile64(tHm, hm, l31, half);
       wave_lds_sync();
       CellOut co;
-      if (p.giT) gru_cell<true>(co, lds, m, p.giT, B, col, ok, tHm, l31, half);
-      else gru_cell<false>(co, lds, m, p.xT, B, col, ok, tHm, l31, half);
+      gru_cell<PRE_GI>(co, lds, m, PRE_GI ? p.giT : p.xT, B, col, ok, tHm, l31, half);
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
         store_fm(base + SCR_GHN * comp, p.Nc, c, co.ghn, ok, half);
         store_fm(base + SCR_HS * comp, p.Nc, c, h, ok, half);
       }
-      if (p.head_mode != 0) {
+      if (HM != 0) {
         float mean, rstd;
         ln_stats(h, mean, rstd);
         f32x16 xh[2];
@@ -354,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
         head_to_tile(tZ, z, p.A, l31, half);
         wave_lds_sync();
         const int64_t row0 = (int64_t)t * p.Nc + tile * TS;
-        if (p.head_mode == 1) {
+        if (HM == 1) {
           for (int e = lane; e < n_valid * p.A; e += WAVE) {
             const int s = e / p.A, a = e - s * p.A;
             p.out[row0 * p.A + e] = tZ[s * TP + a];
@@ -397,6 +400,8 @@ struct GruBwdArgs {
   double *partials;           // [gridDim.x][4]
 };
 
+// HEAD 1 actor | 2 critic loss; DX: compute d x in the kernel (false: deferred to gru_dx_kernel) — compile-time, see gru_fwd_kernel
+template <int HEAD, bool DX>
 __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
   extern __shared__ __align__(16) float lds[];
   __shared__ double red_smem[16 * 4];
@@ -404,7 +409,7 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
   const NetOff &o = p.off;
   const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
   const int A = p.A;
-  stage_gru_all(lds, m, p.params, o, A, p.dxT != nullptr, true);
+  stage_gru_all(lds, m, p.params, o, A, DX, true);
   __syncthreads();
   float *tG = lds + m.tiles;                 // [192][TP]  d gi / d gh (B operand of the W^T products)
   float *tN = tG + NG * TP;                  // [64][TP]   normalised state, then scratch
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
       regs_to_tile64(tN, xh, l31, half);
       wave_lds_sync();
       const f32x16 z = gru_head(lds, m, tN, l31, half);
-      if (p.head == 1) {
+      if (HEAD == 1) {
         head_to_tile(tZ, z, A, l31, half);
         wave_lds_sync();
         if (lane < TS) {
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
       // tG <- d gi  [g][s]
       regs_to_tile64(tG, d_r, l31, half);
       regs_to_tile64(tG + HID * TP, d_z, l31, half);
-      if (p.dxT) {                              // d x_t = W_ih^T . d gi here; NULL: deferred to mappo_gru_input_backward
+      if (DX) {                                 // d x_t = W_ih^T . d gi here; otherwise deferred to mappo_gru_input_backward
         regs_to_tile64(tG + 2 * HID * TP, d_n, l31, half);
         wave_lds_sync();
         f32x16 dx[2];
@@ -843,11 +848,17 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   a.map = gru_lds(nw, wave_rows, giT == nullptr);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_forward: needs %zu B of LDS", lds_bytes);
-  static bool attr = false;
-  if (!attr) { if (int rc = raise_lds(gru_fwd_kernel, "gru_forward")) return rc; attr = true; }
   int nb = (n_tiles + nw - 1) / nw;
   if (nb > NUM_CU) nb = NUM_CU;
-  hipLaunchKernelGGL(gru_fwd_kernel, dim3(nb), dim3(WAVE * nw), lds_bytes, as_stream(stream), a);
+#define GRU_FWD(PRE, HM_)                                                                                         \
+  do {                                                                                                            \
+    static bool attr = false;                                                                                     \
+    if (!attr) { if (int rc = raise_lds(gru_fwd_kernel<PRE, HM_>, "gru_forward")) return rc; attr = true; }       \
+    hipLaunchKernelGGL((gru_fwd_kernel<PRE, HM_>), dim3(nb), dim3(WAVE * nw), lds_bytes, as_stream(stream), a);   \
+  } while (0)
+  if (giT) { if (head_mode == 0) GRU_FWD(true, 0); else if (head_mode == 1) GRU_FWD(true, 1); else GRU_FWD(true, 2); }
+  else { if (head_mode == 0) GRU_FWD(false, 0); else if (head_mode == 1) GRU_FWD(false, 1); else GRU_FWD(false, 2); }
+#undef GRU_FWD
   MAPPO_CHECK_LAUNCH("gru_forward");
   return MAPPO_OK;
 }
@@ -879,10 +890,16 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
   a.map = gru_lds(1, NG + HID + TS, dxT != nullptr);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_backward: needs %zu B of LDS", lds_bytes);
-  static bool attr = false;
-  if (!attr) { if (int rc = raise_lds(gru_bwd_kernel, "gru_backward")) return rc; attr = true; }
   const int nb = mappo_gru_backward_slabs(Nc);
-  hipLaunchKernelGGL(gru_bwd_kernel, dim3(nb), dim3(WAVE), lds_bytes, as_stream(stream), a);
+#define GRU_BWD(H_, DX_)                                                                                          \
+  do {                                                                                                            \
+    static bool attr = false;                                                                                     \
+    if (!attr) { if (int rc = raise_lds(gru_bwd_kernel<H_, DX_>, "gru_backward")) return rc; attr = true; }       \
+    hipLaunchKernelGGL((gru_bwd_kernel<H_, DX_>), dim3(nb), dim3(WAVE), lds_bytes, as_stream(stream), a);         \
+  } while (0)
+  if (head == 1) { if (dxT) GRU_BWD(1, true); else GRU_BWD(1, false); }
+  else { if (dxT) GRU_BWD(2, true); else GRU_BWD(2, false); }
+#undef GRU_BWD
   MAPPO_CHECK_LAUNCH("gru_backward");
   return MAPPO_OK;
 }
