@@ -400,6 +400,104 @@ struct GruBwdArgs {
   double *partials;           // [gridDim.x][4]
 };
 
+// ---- the row-local part of one backward step: y = LayerNorm(h'_t) -> head -> PPO loss -> d h'_t (without the recurrent term) ----
+// One wave, 32 rows (hsT: feature-major h' of step t, column c); accumulates the head / rnn.norm gradients and loss sums.
+template <int HEAD>
+__device__ __forceinline__ void gru_head_backward(f32x16 (&dh)[2], const GruBwdArgs &p, const float *lds, const GruLds &m, float *tN, float *tZ,
+                                                  const LossScales &ls, const float *__restrict__ hsT, int c, bool ok, int64_t brow, int lane,
+                                                  int l31, int half, f32x16 (&gWh)[2], float &gBh, float &gNw, float &gNb, double (&lacc)[4]) {
+  const int A = p.A;
+  // ---- y = LayerNorm(h'_t) -> head -> loss gradient at the head ----
+  f32x16 hs[2];
+  load_fm(hs, hsT, p.Nc, c, ok, half);
+  float mean, rstd;
+  ln_stats(hs, mean, rstd);
+  f32x16 xh[2];
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xh[tt][r] = (hs[tt][r] - mean) * rstd;
+  regs_to_tile64(tN, xh, l31, half);
+  wave_lds_sync();
+  const f32x16 z = gru_head(lds, m, tN, l31, half);
+  if (HEAD == 1) {
+    head_to_tile(tZ, z, A, l31, half);
+    wave_lds_sync();
+    if (lane < TS) {
+      float *zl = tZ + lane * TP;
+      if (ok) {
+        uint32_t dead = 0u;
+        if (p.avail) {
+          const float *av = p.avail + brow * A;
+          for (int a = 0; a < A; ++a) dead |= (av[a] == 0.f ? 1u : 0u) << a;
+        }
+        actor_loss_lane(zl, A, dead, (int)p.actions[brow], p.old_logp[brow], p.adv[brow], p.active[brow], p.cfg, ls.scale_pi, lacc);
+      } else {
+        for (int a = 0; a < A; ++a) zl[a] = 0.f;
+      }
+    }
+  } else if (lane < TS) {
+    float dvv = 0.f;
+    if (ok) dvv = critic_loss_lane(z[0], p.v_old[brow], p.returns[brow], p.active[brow], p.cfg, ls, lacc);
+    tZ[lane * TP] = dvv;
+  }
+  wave_lds_sync();
+  // ---- head weight / bias gradients and d y = Wh^T dz ----
+  f32x16 dH[2];
+  {
+    const float *sG = lds + m.nw, *sBt = lds + m.nb;
+    const float g0 = sG[l31], c0 = sBt[l31], g1 = sG[32 + l31], c1 = sBt[32 + l31];
+    float bsum = 0.f;
+#pragma unroll 4
+    for (int ss = 0; ss < TS / 2; ++ss) {
+      const int s = 2 * ss + half;
+      const float av = (l31 < A) ? tZ[s * TP + l31] : 0.f;
+      bsum += av;
+      gWh[0] = mfma(av, tN[l31 * TP + s] * g0 + c0, gWh[0]);
+      gWh[1] = mfma(av, tN[(32 + l31) * TP + s] * g1 + c1, gWh[1]);
+    }
+    gBh += xhalf_sum(bsum);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dH[tt][r] = 0.f;
+    const float *sW = lds + m.wh;
+    for (int kk = 0; kk < (A + 1) / 2; ++kk) {
+      const int a = 2 * kk + half;
+      const float b = (a < A) ? tZ[l31 * TP + a] : 0.f;
+      dH[0] = mfma(sW[l31 * HP + a], b, dH[0]);
+      dH[1] = mfma(sW[(32 + l31) * HP + a], b, dH[1]);
+    }
+  }
+  wave_lds_sync();
+  // ---- LayerNorm backward (rnn.norm): row sums through the tN tile, then d h' ----
+  regs_to_tile64(tN, dH, l31, half);
+  wave_lds_sync();
+  { float s0 = 0.f; for (int j = 0; j < TS; ++j) s0 += tN[lane * TP + j]; gNb += s0; }
+  wave_lds_sync();
+  float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * tt + ROWMAP(r, half);
+      tN[f * TP + l31] = dH[tt][r] * xh[tt][r];
+      const float dxh = dH[tt][r] * lds[m.nw + f];
+      dH[tt][r] = dxh;
+      m1 += dxh; m2 += dxh * xh[tt][r];
+    }
+  wave_lds_sync();
+  { float s0 = 0.f; for (int j = 0; j < TS; ++j) s0 += tN[lane * TP + j]; gNw += s0; }
+  wave_lds_sync();
+  m1 = xhalf_sum(m1) * (1.f / HID);
+  m2 = xhalf_sum(m2) * (1.f / HID);
+  // LN backward: d h'_t, the recurrent term is added by the caller
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dh[tt][r] = rstd * (dH[tt][r] - m1 - xh[tt][r] * m2);
+}
+
 // HEAD 1 actor | 2 critic loss; DX: compute d x in the kernel (false: deferred to gru_dx_kernel) — compile-time, see gru_fwd_kernel
 template <int HEAD, bool DX>
 __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
@@ -438,96 +536,12 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
       const int64_t col = (int64_t)t * p.Nc + c;
       const float *sb = p.scratch + (int64_t)t * HID * p.Nc;
       const int64_t brow = ok ? (p.rows ? (int64_t)p.rows[col] : col) : 0;
-      // ---- y = LayerNorm(h'_t) -> head -> loss gradient at the head ----
-      f32x16 hs[2];
-      load_fm(hs, sb + SCR_HS * comp, p.Nc, c, ok, half);
-      float mean, rstd;
-      ln_stats(hs, mean, rstd);
-      f32x16 xh[2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xh[tt][r] = (hs[tt][r] - mean) * rstd;
-      regs_to_tile64(tN, xh, l31, half);
-      wave_lds_sync();
-      const f32x16 z = gru_head(lds, m, tN, l31, half);
-      if (HEAD == 1) {
-        head_to_tile(tZ, z, A, l31, half);
-        wave_lds_sync();
-        if (lane < TS) {
-          float *zl = tZ + lane * TP;
-          if (ok) {
-            uint32_t dead = 0u;
-            if (p.avail) {
-              const float *av = p.avail + brow * A;
-              for (int a = 0; a < A; ++a) dead |= (av[a] == 0.f ? 1u : 0u) << a;
-            }
-            actor_loss_lane(zl, A, dead, (int)p.actions[brow], p.old_logp[brow], p.adv[brow], p.active[brow], p.cfg, ls.scale_pi, lacc);
-          } else {
-            for (int a = 0; a < A; ++a) zl[a] = 0.f;
-          }
-        }
-      } else if (lane < TS) {
-        float dvv = 0.f;
-        if (ok) dvv = critic_loss_lane(z[0], p.v_old[brow], p.returns[brow], p.active[brow], p.cfg, ls, lacc);
-        tZ[lane * TP] = dvv;
-      }
-      wave_lds_sync();
-      // ---- head weight / bias gradients and d y = Wh^T dz ----
-      f32x16 dH[2];
-      {
-        const float *sG = lds + m.nw, *sBt = lds + m.nb;
-        const float g0 = sG[l31], c0 = sBt[l31], g1 = sG[32 + l31], c1 = sBt[32 + l31];
-        float bsum = 0.f;
-#pragma unroll 4
-        for (int ss = 0; ss < TS / 2; ++ss) {
-          const int s = 2 * ss + half;
-          const float av = (l31 < A) ? tZ[s * TP + l31] : 0.f;
-          bsum += av;
-          gWh[0] = mfma(av, tN[l31 * TP + s] * g0 + c0, gWh[0]);
-          gWh[1] = mfma(av, tN[(32 + l31) * TP + s] * g1 + c1, gWh[1]);
-        }
-        gBh += xhalf_sum(bsum);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dH[tt][r] = 0.f;
-        const float *sW = lds + m.wh;
-        for (int kk = 0; kk < (A + 1) / 2; ++kk) {
-          const int a = 2 * kk + half;
-          const float b = (a < A) ? tZ[l31 * TP + a] : 0.f;
-          dH[0] = mfma(sW[l31 * HP + a], b, dH[0]);
-          dH[1] = mfma(sW[(32 + l31) * HP + a], b, dH[1]);
-        }
-      }
-      wave_lds_sync();
-      // ---- LayerNorm backward (rnn.norm): row sums through the tN tile, then d h' ----
-      regs_to_tile64(tN, dH, l31, half);
-      wave_lds_sync();
-      { float s0 = 0.f; for (int j = 0; j < TS; ++j) s0 += tN[lane * TP + j]; gNb += s0; }
-      wave_lds_sync();
-      float m1 = 0.f, m2 = 0.f;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int f = 32 * tt + ROWMAP(r, half);
-          tN[f * TP + l31] = dH[tt][r] * xh[tt][r];
-          const float dxh = dH[tt][r] * lds[m.nw + f];
-          dH[tt][r] = dxh;
-          m1 += dxh; m2 += dxh * xh[tt][r];
-        }
-      wave_lds_sync();
-      { float s0 = 0.f; for (int j = 0; j < TS; ++j) s0 += tN[lane * TP + j]; gNw += s0; }
-      wave_lds_sync();
-      m1 = xhalf_sum(m1) * (1.f / HID);
-      m2 = xhalf_sum(m2) * (1.f / HID);
-      // d h'_t = LN backward + carry from step t+1
       f32x16 dh[2];
+      gru_head_backward<HEAD>(dh, p, lds, m, tN, tZ, ls, sb + SCR_HS * comp, c, ok, brow, lane, l31, half, gWh, gBh, gNw, gNb, lacc);
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dh[tt][r] = rstd * (dH[tt][r] - m1 - xh[tt][r] * m2) + carry[tt][r];
+        for (int r = 0; r < 16; ++r) dh[tt][r] += carry[tt][r];
       // ---- cell backward ----
       f32x16 hm[2], gr[2], gz[2], gn[2], ghn[2];
       load_fm(hm, sb + SCR_HM * comp, p.Nc, c, ok, half);
@@ -620,6 +634,290 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
   if (half == 0 && l31 < A) slab[o.bh + l31] = gBh;
   slab[o.rn_w + lane] = gNw;
   slab[o.rn_b + lane] = gNb;
+}
+
+// ---- training path, split three ways -------------------------------------------------------------------
+// The sequential kernels above give one wave 32 sequences and all 64 hidden features: at BASELINE config 2 that is 240
+// lone waves, each paying every load latency, MFMA chain and store burst of a step back to back.  Training therefore runs
+//   gru_head_bwd_kernel   the row-local half of the backward (LayerNorm, head, PPO loss, LayerNorm backward): no
+//                         recurrence in it, so it runs over all L x Nc rows at once and leaves d h'_t (without the
+//                         recurrent term) where the forward stored h'_t;
+//   gru_fwd_train2_kernel / gru_cell_bwd2_kernel
+//                         the recurrences proper, a workgroup of TWO waves per 32 sequences: wave w owns hidden features
+//                         [32 w, 32 w + 32) — its gate rows, its half of the state, half of every load and store, half of
+//                         the MFMAs.  The waves meet once per step, at the LDS tile that holds the step's B operand
+//                         (h_{t-1} * mask, or the step's d gates); the tile is double-buffered, so one barrier per step.
+// Accumulation orders are those of the one-wave kernels: same values bit for bit (up to the order of the slab sums).
+
+struct SeqLds { int whh, bhh, tiles, tile_stride, total; };
+__host__ __device__ inline SeqLds seq2_lds(int tile_rows) {
+  SeqLds m;
+  int p = 0;
+  m.whh = p; p = al4(p + HID * GS);
+  m.bhh = p; p += NG;
+  m.tiles = p;
+  m.tile_stride = al4(tile_rows * TP);
+  p += 2 * m.tile_stride;
+  m.total = p;
+  return m;
+}
+
+// 16 registers of one wave's feature half: feature 32 w + ROWMAP(r, half) of sequence column `col`
+__device__ __forceinline__ void load_fm1(f32x16 &v, const float *__restrict__ src, int64_t ld, int64_t col, int w, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) v[r] = src[(int64_t)(32 * w + ROWMAP(r, half)) * ld + col];
+}
+__device__ __forceinline__ void store_fm1(float *__restrict__ dst, int64_t ld, int64_t col, const f32x16 &v, bool ok, int w, int half) {
+  if (!ok) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) dst[(int64_t)(32 * w + ROWMAP(r, half)) * ld + col] = v[r];
+}
+__device__ __forceinline__ void regs_to_tile1(float *tile, const f32x16 &v, int w, int l31, int half) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) tile[(32 * w + ROWMAP(r, half)) * TP + l31] = v[r];
+}
+
+// forward recurrence of the training pass (input gates precomputed, all per-step gate values stored for the backward)
+__global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, SeqLds m) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
+  stage_gru_weight(lds + m.whh, p.params + p.off.gru_whh);
+  for (int e = threadIdx.x; e < NG; e += blockDim.x) lds[m.bhh + e] = p.params[p.off.gru_bhh + e];
+  __syncthreads();
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t comp = (int64_t)p.L * HID * p.Nc;
+  const int n_tiles = (p.Nc + TS - 1) / TS;
+  f32x16 b_r, b_z, b_n;                                  // b_hh of this wave's gate rows
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int f = 32 * w + ROWMAP(r, half);
+    b_r[r] = lds[m.bhh + f]; b_z[r] = lds[m.bhh + HID + f]; b_n[r] = lds[m.bhh + 2 * HID + f];
+  }
+  const float *sH = lds + m.whh + 32 * w + l31;          // A operand: W_hh[g = gate*64 + 32 w + l31][k] at sH[k*GS + gate*64]
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int c = tile * TS + l31;
+    const bool ok = c < p.Nc;
+    const int cc = ok ? c : 0;
+    f32x16 h;
+    {
+      const int64_t row = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4 *>(p.h0 + row * HID + 32 * w + 8 * q + 4 * half);
+        h[4 * q + 0] = v.x; h[4 * q + 1] = v.y; h[4 * q + 2] = v.z; h[4 * q + 3] = v.w;
+      }
+    }
+    f32x16 gi_r, gi_z, gi_n;
+    load_fm1(gi_r, p.giT, B, cc, w, half);
+    load_fm1(gi_z, p.giT + (int64_t)HID * B, B, cc, w, half);
+    load_fm1(gi_n, p.giT + (int64_t)2 * HID * B, B, cc, w, half);
+    for (int t = 0; t < p.L; ++t) {
+      const int64_t col = (int64_t)t * p.Nc + cc;
+      const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[col] : col] : 0.f;
+      float *tH = lds + m.tiles + (t & 1) * m.tile_stride;      // [64][TP] h_{t-1} * mask
+      f32x16 hm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hm[r] = h[r] * mk;
+      regs_to_tile1(tH, hm, w, l31, half);
+      // next step's input gates: in flight under this step's products (the last step re-reads its own)
+      const int64_t ncol = (int64_t)min(t + 1, p.L - 1) * p.Nc + cc;
+      f32x16 nx_r, nx_z, nx_n;
+      load_fm1(nx_r, p.giT, B, ncol, w, half);
+      load_fm1(nx_z, p.giT + (int64_t)HID * B, B, ncol, w, half);
+      load_fm1(nx_n, p.giT + (int64_t)2 * HID * B, B, ncol, w, half);
+      __syncthreads();
+      f32x16 ar, az, ahn = b_n;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ar[r] = gi_r[r] + b_r[r]; az[r] = gi_z[r] + b_z[r]; }
+#pragma unroll 4
+      for (int kk = 0; kk < HID / 2; ++kk) {
+        const int k = 2 * kk + half;
+        const float bh = tH[k * TP + l31];
+        ar = mfma(sH[k * GS], bh, ar);
+        az = mfma(sH[k * GS + HID], bh, az);
+        ahn = mfma(sH[k * GS + 2 * HID], bh, ahn);
+      }
+      f32x16 gr, gz, gn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        gr[r] = sigmoidf_(ar[r]);
+        gz[r] = sigmoidf_(az[r]);
+        gn[r] = tanhf(gi_n[r] + gr[r] * ahn[r]);
+        h[r] = (1.f - gz[r]) * gn[r] + gz[r] * hm[r];
+      }
+      float *base = p.scratch + (int64_t)t * HID * p.Nc;
+      store_fm1(base + SCR_HM * comp, p.Nc, c, hm, ok, w, half);
+      store_fm1(base + SCR_R * comp, p.Nc, c, gr, ok, w, half);
+      store_fm1(base + SCR_Z * comp, p.Nc, c, gz, ok, w, half);
+      store_fm1(base + SCR_N * comp, p.Nc, c, gn, ok, w, half);
+      store_fm1(base + SCR_GHN * comp, p.Nc, c, ahn, ok, w, half);
+      store_fm1(base + SCR_HS * comp, p.Nc, c, h, ok, w, half);
+      gi_r = nx_r; gi_z = nx_z; gi_n = nx_n;
+    }
+    if (p.h_last && ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4 *>(p.h_last + (int64_t)c * HID + 32 * w + 8 * q + 4 * half) =
+            make_float4(h[4 * q + 0], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+    }
+    __syncthreads();                                     // the next tile's first step may reuse the buffer read last
+  }
+}
+
+// row-local half of the backward over all L x Nc rows; d h' replaces h' in the forward's scratch (component SCR_HS)
+struct HeadLds { GruLds g; int n_waves; };
+#define HEAD_BWD_WAVES 8
+template <int HEAD>
+__global__ __launch_bounds__(WAVE * HEAD_BWD_WAVES, 1) void gru_head_bwd_kernel(GruBwdArgs p, float *dhT) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ double red_smem[16 * 4];
+  const GruLds &m = p.map;
+  const NetOff &o = p.off;
+  const int n_waves = blockDim.x / WAVE;
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
+  const int A = p.A;
+  {
+    const int nthr = blockDim.x, tid = threadIdx.x;
+    for (int e = tid; e < HID; e += nthr) { lds[m.nw + e] = p.params[o.rn_w + e]; lds[m.nb + e] = p.params[o.rn_b + e]; }
+    for (int e = tid; e < 32; e += nthr) lds[m.bh + e] = e < A ? p.params[o.bh + e] : 0.f;
+    for (int e = tid; e < HID * 32; e += nthr) {
+      const int a = e >> 6, k = e & 63;
+      lds[m.wh + k * HP + a] = (a < A) ? p.params[o.wh + a * HID + k] : 0.f;
+    }
+  }
+  __syncthreads();
+  float *tN = lds + m.tiles + wave * m.wave_stride;      // [64][TP]
+  float *tZ = tN + HID * TP;                             // [32][TP]
+  const int64_t comp = (int64_t)p.L * HID * p.Nc;
+  const LossScales ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
+  double lacc[4] = {0.0, 0.0, 0.0, 0.0};
+  f32x16 gWh[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gWh[i][r] = 0.f;
+  float gBh = 0.f, gNw = 0.f, gNb = 0.f;
+  const int n_ct = (p.Nc + TS - 1) / TS, n_tiles = p.L * n_ct;
+  for (int tile = blockIdx.x * n_waves + wave; tile < n_tiles; tile += gridDim.x * n_waves) {
+    const int t = tile / n_ct, c = (tile - t * n_ct) * TS + l31;
+    const bool ok = c < p.Nc;
+    const int64_t col = (int64_t)t * p.Nc + c;
+    const int64_t brow = ok ? (p.rows ? (int64_t)p.rows[col] : col) : 0;
+    const int64_t hs_off = SCR_HS * comp + (int64_t)t * HID * p.Nc;
+    f32x16 dh[2];
+    gru_head_backward<HEAD>(dh, p, lds, m, tN, tZ, ls, p.scratch + hs_off, c, ok, brow, lane, l31, half, gWh, gBh, gNw, gNb, lacc);
+    store_fm(dhT + hs_off, p.Nc, c, dh, ok, half);
+  }
+  // ---- loss partial sums; the waves' head / rnn.norm gradients meet in LDS, wave 0 writes the workgroup's slab ----
+  block_sum<4>(lacc, red_smem);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p.partials[(size_t)blockIdx.x * 4 + k] = lacc[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tN[(16 * tj + r) * WAVE + lane] = gWh[tj][r];
+  tZ[lane] = gBh; tZ[WAVE + lane] = gNw; tZ[2 * WAVE + lane] = gNb;
+  __syncthreads();
+  if (wave != 0) return;
+  for (int ww = 1; ww < n_waves; ++ww) {
+    const float *oN = lds + m.tiles + ww * m.wave_stride, *oZ = oN + HID * TP;
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) gWh[tj][r] += oN[(16 * tj + r) * WAVE + lane];
+    gBh += oZ[lane]; gNw += oZ[WAVE + lane]; gNb += oZ[2 * WAVE + lane];
+  }
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
+#pragma unroll
+  for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = ROWMAP(r, half);
+      if (a < A) slab[o.wh + a * HID + 32 * tj + l31] = gWh[tj][r];
+    }
+  if (half == 0 && l31 < A) slab[o.bh + l31] = gBh;
+  slab[o.rn_w + lane] = gNw;
+  slab[o.rn_b + lane] = gNb;
+}
+
+// backward recurrence: d h'_t (from gru_head_bwd_kernel) + carry -> d gates -> carry = (W_hh^T d gh + d h' z) * mask
+__global__ __launch_bounds__(128, 1) void gru_cell_bwd2_kernel(GruBwdArgs p, SeqLds m) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
+  stage_gru_weight(lds + m.whh, p.params + p.off.gru_whh);
+  __syncthreads();
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t comp = (int64_t)p.L * HID * p.Nc;
+  const int n_tiles = (p.Nc + TS - 1) / TS;
+  const float *sH = lds + m.whh + (32 * w + l31) * GS;   // A operand of W_hh^T: W_hh[g][k = 32 w + l31] at sH[g]
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int c = tile * TS + l31;
+    const bool ok = c < p.Nc;
+    const int cc = ok ? c : 0;
+    f32x16 carry;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) carry[r] = 0.f;
+    f32x16 dh, hm, gr, gz, gn, ghn;
+    {
+      const float *sb = p.scratch + (int64_t)(p.L - 1) * HID * p.Nc;
+      load_fm1(dh, sb + SCR_HS * comp, p.Nc, cc, w, half);
+      load_fm1(hm, sb + SCR_HM * comp, p.Nc, cc, w, half);
+      load_fm1(gr, sb + SCR_R * comp, p.Nc, cc, w, half);
+      load_fm1(gz, sb + SCR_Z * comp, p.Nc, cc, w, half);
+      load_fm1(gn, sb + SCR_N * comp, p.Nc, cc, w, half);
+      load_fm1(ghn, sb + SCR_GHN * comp, p.Nc, cc, w, half);
+    }
+    for (int t = p.L - 1; t >= 0; --t) {
+      const int64_t col = (int64_t)t * p.Nc + cc;
+      const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[col] : col] : 0.f;
+      float *tG = lds + m.tiles + (t & 1) * m.tile_stride;      // [192][TP] d gh of the step (r, z, n rows)
+      // the previous step's values: in flight under this step's work (step 0 re-reads its own)
+      f32x16 n_dh, n_hm, n_r, n_z, n_n, n_ghn;
+      {
+        const float *sb = p.scratch + (int64_t)max(t - 1, 0) * HID * p.Nc;
+        load_fm1(n_dh, sb + SCR_HS * comp, p.Nc, cc, w, half);
+        load_fm1(n_hm, sb + SCR_HM * comp, p.Nc, cc, w, half);
+        load_fm1(n_r, sb + SCR_R * comp, p.Nc, cc, w, half);
+        load_fm1(n_z, sb + SCR_Z * comp, p.Nc, cc, w, half);
+        load_fm1(n_n, sb + SCR_N * comp, p.Nc, cc, w, half);
+        load_fm1(n_ghn, sb + SCR_GHN * comp, p.Nc, cc, w, half);
+      }
+      f32x16 d_r, d_z, d_n, d_hn;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float dhh = (ok ? dh[r] : 0.f) + carry[r], zz = gz[r], nn = gn[r], rr = gr[r];
+        dh[r] = dhh;
+        const float dn_pre = dhh * (1.f - zz) * (1.f - nn * nn);
+        d_n[r] = dn_pre;
+        d_hn[r] = dn_pre * rr;
+        d_r[r] = dn_pre * ghn[r] * rr * (1.f - rr);
+        d_z[r] = dhh * (hm[r] - nn) * zz * (1.f - zz);
+      }
+      regs_to_tile1(tG, d_r, w, l31, half);
+      regs_to_tile1(tG + HID * TP, d_z, w, l31, half);
+      regs_to_tile1(tG + 2 * HID * TP, d_hn, w, l31, half);
+      store_fm1(p.dgiT, B, col, d_r, ok, w, half);
+      store_fm1(p.dgiT + (int64_t)HID * B, B, col, d_z, ok, w, half);
+      store_fm1(p.dgiT + (int64_t)2 * HID * B, B, col, d_n, ok, w, half);
+      store_fm1(p.dghnT, B, col, d_hn, ok, w, half);
+      __syncthreads();
+      f32x16 dhm;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dhm[r] = 0.f;
+#pragma unroll 4
+      for (int gg = 0; gg < NG / 2; ++gg) {
+        const int g = 2 * gg + half;
+        dhm = mfma(sH[g], tG[g * TP + l31], dhm);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) carry[r] = (dhm[r] + dh[r] * gz[r]) * mk;
+      dh = n_dh; hm = n_hm; gr = n_r; gz = n_z; gn = n_n; ghn = n_ghn;
+    }
+    __syncthreads();
+  }
 }
 
 // ---- weight-gradient kernel ---------------------------------------------------------------------------
@@ -842,6 +1140,15 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   a.avail = avail; a.actions = actions; a.logp = logp; a.deterministic = deterministic; a.seed = seed; a.counter = counter;
   a.counter_dev = counter_dev;
   const int n_tiles = (Nc + TS - 1) / TS;
+  if (giT && head_mode == 0 && scratch) {                 // training pass: two waves per 32 sequences
+    const SeqLds sm = seq2_lds(HID);
+    const size_t bytes = (size_t)sm.total * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) { if (int rc = raise_lds(gru_fwd_train2_kernel, "gru_forward")) return rc; attr2 = true; }
+    hipLaunchKernelGGL(gru_fwd_train2_kernel, dim3(n_tiles < 4 * NUM_CU ? n_tiles : 4 * NUM_CU), dim3(2 * WAVE), bytes, as_stream(stream), a, sm);
+    MAPPO_CHECK_LAUNCH("gru_forward");
+    return MAPPO_OK;
+  }
   int nw = head_mode ? 2 : 4;
   while (nw > 1 && n_tiles < nw) nw >>= 1;
   const int wave_rows = head_mode ? (HID + HID + TS) : HID;
@@ -887,18 +1194,55 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
   a.v_old = v_old; a.returns = returns; a.vn_state = vn_state; a.mb_moments = mb_moments; a.cfg = *cfg; a.dxT = dxT; a.dgiT = dgiT;
   a.dghnT = dghnT; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0; a.partials = partials;
   MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru_backward: slab column range");
-  a.map = gru_lds(1, NG + HID + TS, dxT != nullptr);
+  const int nb = mappo_gru_backward_slabs(Nc);
+  if (!dxT) {
+    // training: the row-local half over all L x Nc rows (d h' replaces h' in the forward's scratch), then the recurrence
+    const int n_ct = (Nc + TS - 1) / TS;
+    const int64_t n_tiles = (int64_t)L * n_ct;
+    int nw = (int)((n_tiles + nb - 1) / nb);
+    if (nw > HEAD_BWD_WAVES) nw = HEAD_BWD_WAVES;
+    GruLds hm = {};
+    {
+      int q = 0;
+      hm.wh = q; q = al4(q + HID * HP);
+      hm.nw = q; q += HID; hm.nb = q; q += HID;
+      hm.bh = q; q += 32;
+      hm.tiles = q; hm.wave_stride = al4((HID + TS) * TP);
+      q += nw * hm.wave_stride;
+      hm.total = q;
+    }
+    a.map = hm;
+    const size_t hbytes = (size_t)hm.total * sizeof(float);
+    MAPPO_REQUIRE(hbytes <= LDS_DYN_MAX, "gru_backward: needs %zu B of LDS", hbytes);
+    float *dhT = const_cast<float *>(scratch);
+    if (head == 1) {
+      static bool attr = false;
+      if (!attr) { if (int rc = raise_lds(gru_head_bwd_kernel<1>, "gru_backward")) return rc; attr = true; }
+      hipLaunchKernelGGL(gru_head_bwd_kernel<1>, dim3(nb), dim3(WAVE * nw), hbytes, as_stream(stream), a, dhT);
+    } else {
+      static bool attr = false;
+      if (!attr) { if (int rc = raise_lds(gru_head_bwd_kernel<2>, "gru_backward")) return rc; attr = true; }
+      hipLaunchKernelGGL(gru_head_bwd_kernel<2>, dim3(nb), dim3(WAVE * nw), hbytes, as_stream(stream), a, dhT);
+    }
+    MAPPO_CHECK_LAUNCH("gru_backward (head)");
+    const SeqLds sm = seq2_lds(NG);
+    const size_t sbytes = (size_t)sm.total * sizeof(float);
+    static bool attr2 = false;
+    if (!attr2) { if (int rc = raise_lds(gru_cell_bwd2_kernel, "gru_backward")) return rc; attr2 = true; }
+    hipLaunchKernelGGL(gru_cell_bwd2_kernel, dim3(n_ct < 4 * NUM_CU ? n_ct : 4 * NUM_CU), dim3(2 * WAVE), sbytes, as_stream(stream), a, sm);
+    MAPPO_CHECK_LAUNCH("gru_backward (cell)");
+    return MAPPO_OK;
+  }
+  a.map = gru_lds(1, NG + HID + TS, true);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_backward: needs %zu B of LDS", lds_bytes);
-  const int nb = mappo_gru_backward_slabs(Nc);
 #define GRU_BWD(H_, DX_)                                                                                          \
   do {                                                                                                            \
     static bool attr = false;                                                                                     \
     if (!attr) { if (int rc = raise_lds(gru_bwd_kernel<H_, DX_>, "gru_backward")) return rc; attr = true; }       \
     hipLaunchKernelGGL((gru_bwd_kernel<H_, DX_>), dim3(nb), dim3(WAVE), lds_bytes, as_stream(stream), a);         \
   } while (0)
-  if (head == 1) { if (dxT) GRU_BWD(1, true); else GRU_BWD(1, false); }
-  else { if (dxT) GRU_BWD(2, true); else GRU_BWD(2, false); }
+  if (head == 1) GRU_BWD(1, true); else GRU_BWD(2, true);
 #undef GRU_BWD
   MAPPO_CHECK_LAUNCH("gru_backward");
   return MAPPO_OK;
