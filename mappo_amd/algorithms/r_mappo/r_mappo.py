@@ -249,30 +249,45 @@ class R_MAPPO():
         sequence.  With num_mini_batch == 1 the whole sequence (advantages, ppo_epoch updates, after_update) is
         captured into ONE hipGraph after a first eager run and replayed afterwards: the inner loop is a fixed
         chain of ~15 short kernels per update, launch-bound when issued from Python."""
+        self._sync_actor_mode(update_actor)
         if self._use_recurrent_policy or self._use_naive_recurrent:
             from mappo_amd.recurrent import train_recurrent
-            info = train_recurrent(self, buffer, update_actor)
-            if after_update:
-                buffer.after_update()
-            return info
-        static = self.num_mini_batch == 1 and not self._exact_order       # no randperm inside => capturable
+            # the chunk permutation is drawn on the device (graph-safe philox stream), so the ppo_epoch x ~25 launches of
+            # the two networks' chains replay as one hipGraph; the reference's CPU permutation stream stays eager
+            static = buffer.perm_device != "cpu"
+            body = lambda: (train_recurrent(self, buffer, update_actor), buffer.after_update() if after_update else None)
+        else:
+            static = self.num_mini_batch == 1 and not self._exact_order   # no randperm inside => capturable
+            body = lambda: self._train_body(buffer, update_actor, after_update)
         if not (self._use_graph and static and self._dist is None):
-            self._train_body(buffer, update_actor, after_update)
+            body()
             return self._finish_train_info()
         key = (id(buffer), bool(update_actor), bool(after_update))
         state = self._graphs.get(key)
         if state is None:
-            self._train_body(buffer, update_actor, after_update)           # eager: allocates workspaces, sets attributes
+            body()                                                         # eager: allocates workspaces, sets attributes
             self._graphs[key] = "warm"
         else:
             if state == "warm":
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._train_body(buffer, update_actor, after_update)
+                    body()
                 self._graphs[key] = state = g
             state.replay()
         return self._finish_train_info()
+
+    def _sync_actor_mode(self, update_actor):
+        """Host-side switches of update_actor (torch >= 2: grad None => Adam skips the actor), applied eagerly before the
+        launch sequence so that a replayed hipGraph never depends on what the previous train() call was."""
+        if update_actor != self._actor_enabled:
+            self.policy.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
+            self._actor_enabled = update_actor
+        if not update_actor and not self._actor_slabs_clean:
+            for (name, _, _), t in self._ws.items():
+                if name in ("slabs", "slabs_rec"):
+                    t[:, :self.policy.seg_bounds[1]].zero_()
+        self._actor_slabs_clean = not update_actor
 
     def _train_body(self, buffer, update_actor, after_update):
         T = buffer.episode_length

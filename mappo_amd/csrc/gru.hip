@@ -650,14 +650,14 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
 // Accumulation orders are those of the one-wave kernels: same values bit for bit (up to the order of the slab sums).
 
 struct SeqLds { int whh, bhh, tiles, tile_stride, total; };
-__host__ __device__ inline SeqLds seq2_lds(int tile_rows) {
+__host__ __device__ inline SeqLds seq2_lds(int tile_rows, int n_buf) {
   SeqLds m;
   int p = 0;
   m.whh = p; p = al4(p + HID * GS);
   m.bhh = p; p += NG;
   m.tiles = p;
   m.tile_stride = al4(tile_rows * TP);
-  p += 2 * m.tile_stride;
+  p += n_buf * m.tile_stride;
   m.total = p;
   return m;
 }
@@ -766,7 +766,7 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
 
 // row-local half of the backward over all L x Nc rows; d h' replaces h' in the forward's scratch (component SCR_HS)
 struct HeadLds { GruLds g; int n_waves; };
-#define HEAD_BWD_WAVES 8
+#define HEAD_BWD_WAVES 4
 template <int HEAD>
 __global__ __launch_bounds__(WAVE * HEAD_BWD_WAVES, 1) void gru_head_bwd_kernel(GruBwdArgs p, float *dhT) {
   extern __shared__ __align__(16) float lds[];
@@ -873,7 +873,7 @@ __global__ __launch_bounds__(128, 1) void gru_cell_bwd2_kernel(GruBwdArgs p, Seq
     for (int t = p.L - 1; t >= 0; --t) {
       const int64_t col = (int64_t)t * p.Nc + cc;
       const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[col] : col] : 0.f;
-      float *tG = lds + m.tiles + (t & 1) * m.tile_stride;      // [192][TP] d gh of the step (r, z, n rows)
+      float *tG = lds + m.tiles;                                // [192][TP] d gh of the step (r, z, n rows), single-buffered
       // the previous step's values: in flight under this step's work (step 0 re-reads its own)
       f32x16 n_dh, n_hm, n_r, n_z, n_n, n_ghn;
       {
@@ -915,8 +915,8 @@ __global__ __launch_bounds__(128, 1) void gru_cell_bwd2_kernel(GruBwdArgs p, Seq
 #pragma unroll
       for (int r = 0; r < 16; ++r) carry[r] = (dhm[r] + dh[r] * gz[r]) * mk;
       dh = n_dh; hm = n_hm; gr = n_r; gz = n_z; gn = n_n; ghn = n_ghn;
+      __syncthreads();                                   // both waves are done reading the tile
     }
-    __syncthreads();
   }
 }
 
@@ -1141,7 +1141,7 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   a.counter_dev = counter_dev;
   const int n_tiles = (Nc + TS - 1) / TS;
   if (giT && head_mode == 0 && scratch) {                 // training pass: two waves per 32 sequences
-    const SeqLds sm = seq2_lds(HID);
+    const SeqLds sm = seq2_lds(HID, 2);
     const size_t bytes = (size_t)sm.total * sizeof(float);
     static bool attr2 = false;
     if (!attr2) { if (int rc = raise_lds(gru_fwd_train2_kernel, "gru_forward")) return rc; attr2 = true; }
@@ -1225,7 +1225,7 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
       hipLaunchKernelGGL(gru_head_bwd_kernel<2>, dim3(nb), dim3(WAVE * nw), hbytes, as_stream(stream), a, dhT);
     }
     MAPPO_CHECK_LAUNCH("gru_backward (head)");
-    const SeqLds sm = seq2_lds(NG);
+    const SeqLds sm = seq2_lds(NG, 1);    // 75 KB: the actor's and the critic's workgroups share a CU
     const size_t sbytes = (size_t)sm.total * sizeof(float);
     static bool attr2 = false;
     if (!attr2) { if (int rc = raise_lds(gru_cell_bwd2_kernel, "gru_backward")) return rc; attr2 = true; }

@@ -170,7 +170,8 @@ def _buffer_sources(tr, buffer, adv):
 
 
 def train_recurrent(tr, buffer, update_actor=True):
-    """R_MAPPO.train for use_recurrent_policy (chunks of data_chunk_length) / use_naive_recurrent_policy (episodes)."""
+    """R_MAPPO.train for use_recurrent_policy (chunks of data_chunk_length) / use_naive_recurrent_policy (episodes): the launch
+    sequence only, no host synchronisation (R_MAPPO.train captures it into a hipGraph and reads the statistics afterwards)."""
     if buffer.recurrent_N != 1:
         raise NotImplementedError("recurrent_N != 1")
     adv = tr.compute_advantages(buffer)
@@ -186,7 +187,6 @@ def train_recurrent(tr, buffer, update_actor=True):
             batches = buffer.naive_recurrent_rows(tr.num_mini_batch)
         for rows, h0_rows in batches:
             _update_recurrent(tr, src, rows, h0_rows, L, h0_rows.numel(), update_actor)
-    return tr._finish_train_info()
 
 
 def ppo_update_recurrent(tr, sample, update_actor=True):
