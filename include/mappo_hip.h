@@ -69,6 +69,13 @@ int mappo_insert_mpe(const float *obs, int64_t obs_stride_n, int64_t obs_stride_
                      int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones /*bool bytes*/,
                      int64_t done_stride_n, int64_t done_stride_m, float *obs_dst, float *share_dst, float *rew_dst,
                      float *mask_dst, int32_t N, int32_t M, int32_t D, int32_t centralized, mappo_stream_t stream);
+/* The same for recurrent policies (mpe_runner.py:126-128 + shared_buffer.py:96-97): additionally
+ * rnn_dst / rnn_critic_dst [N*M][H] (slot step+1) = rnn_states / rnn_states_critic * (1 - done); H = recurrent_N * hidden. */
+int mappo_insert_mpe_rnn(const float *obs, int64_t obs_stride_n, int64_t obs_stride_m, const float *rewards,
+                         int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones, int64_t done_stride_n,
+                         int64_t done_stride_m, float *obs_dst, float *share_dst, float *rew_dst, float *mask_dst, int32_t N,
+                         int32_t M, int32_t D, int32_t centralized, const float *rnn_states, const float *rnn_states_critic,
+                         float *rnn_dst, float *rnn_critic_dst, int32_t H, mappo_stream_t stream);
 
 /* K1, after_update (shared_buffer.py:114-131): `count` (<= 16) independent fp32 device copies in one launch.
  * dst / src / n_floats are HOST arrays of device pointers / lengths. */

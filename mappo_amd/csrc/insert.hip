@@ -29,6 +29,55 @@ extern "C" int mappo_insert_mpe(const float *obs, int64_t obs_stride_n, int64_t 
   return MAPPO_OK;
 }
 
+// The same insert for recurrent policies: additionally rnn_states / rnn_states_critic of slot step+1 = the states the
+// networks just returned, zeroed where the episode ended (mpe_runner.py:126-128) — one launch instead of the mask cast,
+// two products and two slot copies.
+struct RnnInsert {
+  const float *h_a, *h_c;       // [N*M][H] contiguous
+  float *dst_a, *dst_c;
+  int H;                        // recurrent_N * hidden_size, multiple of 4
+};
+__global__ __launch_bounds__(256) void insert_mpe_rnn_kernel(InsertArgs p, RnnInsert r) {
+  insert_mpe_body(p, blockIdx.x, gridDim.x);
+  const int h4 = r.H >> 2;
+  const int64_t total = (int64_t)p.N * p.M * h4;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nm = e / h4;
+    const int n = (int)(nm / p.M), m = (int)(nm - (int64_t)n * p.M);
+    const float keep = p.done[n * p.done_sn + m * p.done_sm] ? 0.f : 1.f;
+    float4 a = reinterpret_cast<const float4 *>(r.h_a)[e], c = reinterpret_cast<const float4 *>(r.h_c)[e];
+    a.x *= keep; a.y *= keep; a.z *= keep; a.w *= keep;
+    c.x *= keep; c.y *= keep; c.z *= keep; c.w *= keep;
+    reinterpret_cast<float4 *>(r.dst_a)[e] = a;
+    reinterpret_cast<float4 *>(r.dst_c)[e] = c;
+  }
+}
+
+extern "C" int mappo_insert_mpe_rnn(const float *obs, int64_t obs_stride_n, int64_t obs_stride_m, const float *rewards,
+                                    int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones, int64_t done_stride_n,
+                                    int64_t done_stride_m, float *obs_dst, float *share_dst, float *rew_dst, float *mask_dst,
+                                    int32_t N, int32_t M, int32_t D, int32_t centralized, const float *rnn_states,
+                                    const float *rnn_states_critic, float *rnn_dst, float *rnn_critic_dst, int32_t H,
+                                    mappo_stream_t stream) {
+  MAPPO_REQUIRE(obs && rewards && dones && obs_dst && share_dst && rew_dst && mask_dst && N > 0 && M > 0 && D > 0,
+                "insert_mpe_rnn: bad arguments");
+  MAPPO_REQUIRE(rnn_states && rnn_states_critic && rnn_dst && rnn_critic_dst && H > 0 && (H & 3) == 0, "insert_mpe_rnn: bad state arguments");
+  MAPPO_REQUIRE(((((uintptr_t)rnn_states) | ((uintptr_t)rnn_states_critic) | ((uintptr_t)rnn_dst) | ((uintptr_t)rnn_critic_dst)) & 15) == 0,
+                "insert_mpe_rnn: state arrays must be 16-byte aligned");
+  InsertArgs a;
+  a.obs = obs; a.obs_sn = obs_stride_n; a.obs_sm = obs_stride_m; a.rew = rewards; a.rew_sn = rew_stride_n; a.rew_sm = rew_stride_m;
+  a.done = dones; a.done_sn = done_stride_n; a.done_sm = done_stride_m; a.obs_dst = obs_dst; a.share_dst = share_dst;
+  a.rew_dst = rew_dst; a.mask_dst = mask_dst; a.N = N; a.M = M; a.D = D; a.centralized = centralized;
+  RnnInsert r;
+  r.h_a = rnn_states; r.h_c = rnn_states_critic; r.dst_a = rnn_dst; r.dst_c = rnn_critic_dst; r.H = H;
+  const int64_t t1 = (int64_t)N * M * (centralized ? M * D : D), t2 = (int64_t)N * M * (H >> 2);
+  int64_t nb = ((t1 > t2 ? t1 : t2) + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(insert_mpe_rnn_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a, r);
+  MAPPO_CHECK_LAUNCH("insert_mpe_rnn");
+  return MAPPO_OK;
+}
+
 // K1 (after_update, shared_buffer.py:114-131): up to 16 independent device copies in ONE launch (the reference copies
 // slot T of eight arrays back to slot 0; as separate copies each is a launch of a few microseconds).
 #define COPY_MAX 16

@@ -55,6 +55,23 @@ def insert_mpe(obs, rewards, dones, obs_dst, share_dst, rew_dst, mask_dst, centr
     _lib.check(rc, "mappo_insert_mpe")
 
 
+def insert_mpe_rnn(obs, rewards, dones, obs_dst, share_dst, rew_dst, mask_dst, centralized, rnn_states, rnn_states_critic, rnn_dst,
+                   rnn_critic_dst):
+    """insert_mpe + rnn_dst / rnn_critic_dst = states * (1 - done) in the same launch (contiguous fp32 [N*M, H] state arrays)."""
+    N, M, D = obs.shape
+    if rewards.dim() == 3:
+        rewards = rewards[..., 0]
+    assert obs.is_cuda and obs.dtype == torch.float32 and obs.stride(2) == 1 and rewards.dtype == torch.float32 and dones.dtype == torch.bool
+    H = rnn_states.numel() // (N * M)
+    assert rnn_states.numel() == rnn_states_critic.numel() == rnn_dst.numel() == rnn_critic_dst.numel() == N * M * H
+    rc = _lib.load().mappo_insert_mpe_rnn(C.c_void_p(obs.data_ptr()), obs.stride(0), obs.stride(1), C.c_void_p(rewards.data_ptr()),
+                                          rewards.stride(0), rewards.stride(1), C.c_void_p(dones.data_ptr()), dones.stride(0),
+                                          dones.stride(1), _ptr(obs_dst), _ptr(share_dst), _ptr(rew_dst), _ptr(mask_dst), int(N), int(M),
+                                          int(D), int(bool(centralized)), _ptr(rnn_states), _ptr(rnn_states_critic), _ptr(rnn_dst),
+                                          _ptr(rnn_critic_dst), int(H), _stream())
+    _lib.check(rc, "mappo_insert_mpe_rnn")
+
+
 def copy_batch(pairs):
     """[(dst, src), ...] contiguous fp32 device tensors of equal numel per pair, copied in ONE launch (<= 16 pairs)."""
     n = len(pairs)

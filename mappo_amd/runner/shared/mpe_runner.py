@@ -173,7 +173,7 @@ class MPERunner(Runner):
         b = self.buffer
         dev = b.device
         recurrent = self.trainer._use_recurrent_policy or self.trainer._use_naive_recurrent
-        if not recurrent and b.insert_mpe_fused(obs, rewards, dones, self.use_centralized_V):
+        if b.insert_mpe_fused(obs, rewards, dones, self.use_centralized_V, *((rnn_states, rnn_states_critic) if recurrent else ())):
             return                                                                         # one kernel did it all
         obs_t = obs if (torch.is_tensor(obs) and obs.device == dev) else torch.as_tensor(obs, dtype=torch.float32).to(dev)
         dones_t = dones if (torch.is_tensor(dones) and dones.device == dev) else torch.as_tensor(dones).to(dev)

@@ -107,17 +107,26 @@ class SharedReplayBuffer(object):
             self._put(self.available_actions[s + 1], available_actions)
         self.step = (s + 1) % self.episode_length
 
-    def insert_mpe_fused(self, obs, rewards, dones, centralized):
+    def insert_mpe_fused(self, obs, rewards, dones, centralized, rnn_states=None, rnn_states_critic=None):
         """MPE rollout insert as ONE kernel (mappo_insert_mpe): obs / share_obs -> slot step+1, rewards -> slot step,
-        masks = 1 - done -> slot step+1.  Returns False (nothing written) when the inputs are not device tensors of the
-        expected dtypes, so the caller can fall back to the generic slot copies."""
+        masks = 1 - done -> slot step+1; with rnn_states / rnn_states_critic (recurrent policies) also their slot step+1 =
+        states * (1 - done) (mappo_insert_mpe_rnn).  Returns False (nothing written) when the inputs are not device tensors
+        of the expected dtypes, so the caller can fall back to the generic slot copies."""
         ok = (torch.is_tensor(obs) and torch.is_tensor(rewards) and torch.is_tensor(dones) and obs.device == self.device
               and obs.dtype == torch.float32 and obs.dim() == 3 and obs.stride(2) == 1 and rewards.device == self.device
               and rewards.dtype == torch.float32 and dones.device == self.device and dones.dtype == torch.bool and dones.dim() == 2)
+        if rnn_states is not None:
+            state_ok = lambda h: (torch.is_tensor(h) and h.device == self.device and h.dtype == torch.float32 and h.is_contiguous()
+                                  and h.numel() == self.rnn_states[0].numel() and h.data_ptr() % 16 == 0)
+            ok = ok and state_ok(rnn_states) and state_ok(rnn_states_critic) and (self.recurrent_N * self.rnn_states.shape[-1]) % 4 == 0
         if not ok:
             return False
         s = self.step
-        ops.insert_mpe(obs, rewards, dones, self.obs[s + 1], self.share_obs[s + 1], self.rewards[s], self.masks[s + 1], centralized)
+        if rnn_states is not None:
+            ops.insert_mpe_rnn(obs, rewards, dones, self.obs[s + 1], self.share_obs[s + 1], self.rewards[s], self.masks[s + 1],
+                               centralized, rnn_states, rnn_states_critic, self.rnn_states[s + 1], self.rnn_states_critic[s + 1])
+        else:
+            ops.insert_mpe(obs, rewards, dones, self.obs[s + 1], self.share_obs[s + 1], self.rewards[s], self.masks[s + 1], centralized)
         self.step = (s + 1) % self.episode_length
         return True
 

@@ -603,6 +603,30 @@ def test_insert_mpe_kernel(ops, centralized):
 
 
 @pytest.mark.parametrize("centralized", [True, False])
+def test_insert_mpe_rnn_kernel(ops, centralized):
+    """K1, recurrent policies: mappo_insert_mpe_rnn == mappo_insert_mpe + rnn_states * (1 - done) written to the slot
+    (mpe_runner.py:126-128, shared_buffer.py:96-97), bit for bit."""
+    N, M, D, H = 37, 3, 18, 64
+    g = torch.Generator(device="cuda").manual_seed(0)
+    blk = torch.randn(N, M * D + 1, device="cuda", generator=g)
+    obs = blk[:, :M * D].view(N, M, D)
+    rew = blk[:, M * D:].view(N, 1, 1).expand(N, M, 1)
+    dones = torch.rand(N, M, device="cuda", generator=g) > 0.5
+    ha, hc = torch.randn(N * M, 1, H, device="cuda", generator=g), torch.randn(N * M, 1, H, device="cuda", generator=g)
+    S = M * D if centralized else D
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda")
+    od, sd, rd, md, da, dc = nan(N, M, D), nan(N, M, S), nan(N, M, 1), nan(N, M, 1), nan(N, M, 1, H), nan(N, M, 1, H)
+    ops.insert_mpe_rnn(obs, rew, dones, od, sd, rd, md, centralized, ha, hc, da, dc)
+    od2, sd2, rd2, md2 = nan(N, M, D), nan(N, M, S), nan(N, M, 1), nan(N, M, 1)
+    ops.insert_mpe(obs, rew, dones, od2, sd2, rd2, md2, centralized)
+    for a, b in ((od, od2), (sd, sd2), (rd, rd2), (md, md2)):
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+    keep = (~dones).float().view(N, M, 1, 1)
+    np.testing.assert_array_equal(da.cpu().numpy(), (ha.view(N, M, 1, H) * keep).cpu().numpy())
+    np.testing.assert_array_equal(dc.cpu().numpy(), (hc.view(N, M, 1, H) * keep).cpu().numpy())
+
+
+@pytest.mark.parametrize("centralized", [True, False])
 def test_rollout_step_fused_matches_separate_launches(ops, centralized):
     """mappo_rollout_step (one launch: insert of the env output + get_actions + get_values, rows read in place from a
     strided env block) == mappo_insert_mpe, then mappo_actor_act / mappo_mlp_forward on the buffer slots, bit for bit."""
