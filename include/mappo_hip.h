@@ -77,6 +77,17 @@ int mappo_insert_mpe_rnn(const float *obs, int64_t obs_stride_n, int64_t obs_str
                          int32_t M, int32_t D, int32_t centralized, const float *rnn_states, const float *rnn_states_critic,
                          float *rnn_dst, float *rnn_critic_dst, int32_t H, mappo_stream_t stream);
 
+/* K1 for the SMAC runner (smac_runner.py:129-151 + shared_buffer.py:74-112) in one launch.  dones_env[n] = all_m dones[n][m];
+ * masks = 1 - dones_env, active_masks = dones_env ? 1 : 1 - dones, bad_masks = 1 - bad_transition (NULL: all 1),
+ * rnn slots = states * (1 - dones_env) (rnn_states NULL: skipped); obs [N*M][D], share_obs [N*M][S], avail [N*M][A] (or NULL)
+ * and rewards are copied to their slots.  dones / bad_transition are bool bytes. */
+int mappo_insert_smac(const float *obs, const float *share_obs, const float *avail, const float *rewards, int64_t rew_stride_n,
+                      int64_t rew_stride_m, const uint8_t *dones, int64_t done_stride_n, int64_t done_stride_m,
+                      const uint8_t *bad_transition, const float *rnn_states, const float *rnn_states_critic, float *obs_dst,
+                      float *share_dst, float *avail_dst, float *rew_dst, float *mask_dst, float *bad_mask_dst,
+                      float *active_mask_dst, float *rnn_dst, float *rnn_critic_dst, int32_t N, int32_t M, int32_t D, int32_t S,
+                      int32_t A, int32_t H, mappo_stream_t stream);
+
 /* K1, after_update (shared_buffer.py:114-131): `count` (<= 16) independent fp32 device copies in one launch.
  * dst / src / n_floats are HOST arrays of device pointers / lengths. */
 int mappo_copy_batch(int32_t count, float *const *dst, const float *const *src, const int64_t *n_floats, mappo_stream_t stream);

@@ -78,6 +78,79 @@ extern "C" int mappo_insert_mpe_rnn(const float *obs, int64_t obs_stride_n, int6
   return MAPPO_OK;
 }
 
+// The SMAC rollout insert (smac_runner.py:129-151 + shared_buffer.py:74-112) in one launch.  With dones_env[n] = all_m dones[n][m]:
+//   masks = 1 - dones_env (per env, every agent) ; active_masks = dones_env ? 1 : 1 - dones ; bad_masks = 1 - bad_transition ;
+//   rnn_states / rnn_states_critic = states * (1 - dones_env) ; obs, share_obs, available_actions, rewards copied to their slots.
+struct SmacInsert {
+  const float *obs, *share, *avail;              // contiguous [N*M][D | S | A]
+  const float *rew; int64_t rew_sn, rew_sm;
+  const uint8_t *done; int64_t done_sn, done_sm;
+  const uint8_t *bad;                            // contiguous [N*M] bool bytes or NULL (no bad transitions)
+  const float *h_a, *h_c;                        // contiguous [N*M][H] or NULL
+  float *obs_dst, *share_dst, *avail_dst, *rew_dst, *mask_dst, *bad_dst, *active_dst, *ha_dst, *hc_dst;
+  int N, M, D, S, A, H;
+};
+__device__ __forceinline__ bool env_done(const SmacInsert &p, int n) {
+  bool all = true;
+  for (int m = 0; m < p.M; ++m) all = all && p.done[n * p.done_sn + m * p.done_sm] != 0;
+  return all;
+}
+__global__ __launch_bounds__(256) void insert_smac_kernel(SmacInsert p) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  const int64_t R = (int64_t)p.N * p.M;
+  for (int64_t e = tid; e < R * p.D; e += nthr) p.obs_dst[e] = p.obs[e];
+  for (int64_t e = tid; e < R * p.S; e += nthr) p.share_dst[e] = p.share[e];
+  if (p.avail)
+    for (int64_t e = tid; e < R * p.A; e += nthr) p.avail_dst[e] = p.avail[e];
+  for (int64_t e = tid; e < R; e += nthr) {
+    const int n = (int)(e / p.M), m = (int)(e - (int64_t)n * p.M);
+    const bool de = env_done(p, n), d = p.done[n * p.done_sn + m * p.done_sm] != 0;
+    p.rew_dst[e] = p.rew[n * p.rew_sn + m * p.rew_sm];
+    p.mask_dst[e] = de ? 0.f : 1.f;
+    p.active_dst[e] = de ? 1.f : (d ? 0.f : 1.f);
+    p.bad_dst[e] = (p.bad && p.bad[e]) ? 0.f : 1.f;
+  }
+  if (p.h_a) {
+    const int h4 = p.H >> 2;
+    for (int64_t e = tid; e < R * h4; e += nthr) {
+      const int n = (int)((e / h4) / p.M);
+      const float keep = env_done(p, n) ? 0.f : 1.f;
+      float4 a = reinterpret_cast<const float4 *>(p.h_a)[e], c = reinterpret_cast<const float4 *>(p.h_c)[e];
+      a.x *= keep; a.y *= keep; a.z *= keep; a.w *= keep;
+      c.x *= keep; c.y *= keep; c.z *= keep; c.w *= keep;
+      reinterpret_cast<float4 *>(p.ha_dst)[e] = a;
+      reinterpret_cast<float4 *>(p.hc_dst)[e] = c;
+    }
+  }
+}
+
+extern "C" int mappo_insert_smac(const float *obs, const float *share_obs, const float *avail, const float *rewards, int64_t rew_stride_n,
+                                 int64_t rew_stride_m, const uint8_t *dones, int64_t done_stride_n, int64_t done_stride_m,
+                                 const uint8_t *bad_transition, const float *rnn_states, const float *rnn_states_critic, float *obs_dst,
+                                 float *share_dst, float *avail_dst, float *rew_dst, float *mask_dst, float *bad_mask_dst,
+                                 float *active_mask_dst, float *rnn_dst, float *rnn_critic_dst, int32_t N, int32_t M, int32_t D,
+                                 int32_t S, int32_t A, int32_t H, mappo_stream_t stream) {
+  MAPPO_REQUIRE(obs && share_obs && rewards && dones && obs_dst && share_dst && rew_dst && mask_dst && bad_mask_dst && active_mask_dst &&
+                N > 0 && M > 0 && D > 0 && S > 0, "insert_smac: bad arguments");
+  MAPPO_REQUIRE(!avail || (avail_dst && A > 0), "insert_smac: available_actions slot");
+  if (rnn_states) {
+    MAPPO_REQUIRE(rnn_states_critic && rnn_dst && rnn_critic_dst && H > 0 && (H & 3) == 0, "insert_smac: bad state arguments");
+    MAPPO_REQUIRE(((((uintptr_t)rnn_states) | ((uintptr_t)rnn_states_critic) | ((uintptr_t)rnn_dst) | ((uintptr_t)rnn_critic_dst)) & 15) == 0,
+                  "insert_smac: state arrays must be 16-byte aligned");
+  }
+  SmacInsert a;
+  a.obs = obs; a.share = share_obs; a.avail = avail; a.rew = rewards; a.rew_sn = rew_stride_n; a.rew_sm = rew_stride_m;
+  a.done = dones; a.done_sn = done_stride_n; a.done_sm = done_stride_m; a.bad = bad_transition; a.h_a = rnn_states; a.h_c = rnn_states_critic;
+  a.obs_dst = obs_dst; a.share_dst = share_dst; a.avail_dst = avail_dst; a.rew_dst = rew_dst; a.mask_dst = mask_dst; a.bad_dst = bad_mask_dst;
+  a.active_dst = active_mask_dst; a.ha_dst = rnn_dst; a.hc_dst = rnn_critic_dst; a.N = N; a.M = M; a.D = D; a.S = S; a.A = A; a.H = H;
+  int64_t most = (int64_t)N * M * (D > S ? D : S);
+  int64_t nb = (most + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(insert_smac_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a);
+  MAPPO_CHECK_LAUNCH("insert_smac");
+  return MAPPO_OK;
+}
+
 // K1 (after_update, shared_buffer.py:114-131): up to 16 independent device copies in ONE launch (the reference copies
 // slot T of eight arrays back to slot 0; as separate copies each is a launch of a few microseconds).
 #define COPY_MAX 16

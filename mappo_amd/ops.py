@@ -72,6 +72,26 @@ def insert_mpe_rnn(obs, rewards, dones, obs_dst, share_dst, rew_dst, mask_dst, c
     _lib.check(rc, "mappo_insert_mpe_rnn")
 
 
+def insert_smac(obs, share_obs, avail, rewards, dones, bad, rnn_states, rnn_states_critic, obs_dst, share_dst, avail_dst, rew_dst, mask_dst,
+                bad_dst, active_dst, rnn_dst, rnn_critic_dst):
+    """SMAC rollout insert in one launch (mappo_insert_smac): contiguous fp32 obs [N, M, D] / share_obs [N, M, S] / avail [N, M, A] (or
+    None), rewards [N, M(, 1)] (any strides), dones [N, M] bool, bad [N, M] bool contiguous or None, states [N*M, ., H] or None."""
+    N, M, D = obs.shape
+    S = share_obs.shape[-1]
+    if rewards.dim() == 3:
+        rewards = rewards[..., 0]
+    A = avail.shape[-1] if avail is not None else 0
+    H = rnn_states.numel() // (N * M) if rnn_states is not None else 0
+    n = lambda t: _ptr(t, allow_none=True)
+    rc = _lib.load().mappo_insert_smac(_ptr(obs), _ptr(share_obs), n(avail), C.c_void_p(rewards.data_ptr()), rewards.stride(0),
+                                       rewards.stride(1), C.c_void_p(dones.data_ptr()), dones.stride(0), dones.stride(1),
+                                       C.c_void_p(bad.data_ptr()) if bad is not None else None, n(rnn_states), n(rnn_states_critic),
+                                       _ptr(obs_dst), _ptr(share_dst), n(avail_dst), _ptr(rew_dst), _ptr(mask_dst), _ptr(bad_dst),
+                                       _ptr(active_dst), n(rnn_dst), n(rnn_critic_dst), int(N), int(M), int(D), int(S), int(A), int(H),
+                                       _stream())
+    _lib.check(rc, "mappo_insert_smac")
+
+
 def copy_batch(pairs):
     """[(dst, src), ...] contiguous fp32 device tensors of equal numel per pair, copied in ONE launch (<= 16 pairs)."""
     n = len(pairs)

@@ -16,6 +16,11 @@ from .base_runner import Runner, _t2n
 class SMACRunner(Runner):
     def __init__(self, config):
         super(SMACRunner, self).__init__(config)
+        self._rollout_graph = None          # None -> "warm" -> CUDAGraph
+        # a device-resident env without data-dependent host control flow (mappo_amd.envs.synthetic) lets the whole episode
+        # (T x collect / env.step / insert + compute) replay as one hipGraph, as in MPERunner.rollout
+        self._use_graph = (bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False))
+                           and config.get("dist_group") is None)
 
     def run(self):
         self.warmup()
@@ -54,14 +59,35 @@ class SMACRunner(Runner):
     def run_episode(self, episode=0, episodes=1):
         if self.use_linear_lr_decay:
             self.trainer.policy.lr_decay(episode, episodes)
+        infos = self.rollout()
+        return self.train(), infos
+
+    def _rollout_body(self):
         infos = None
+        self.trainer.policy.actor._counter_dev.add_(self.episode_length)   # fresh sampling stream per (replayed) episode
         for step in range(self.episode_length):
             values, actions, action_log_probs, rnn_states, rnn_states_critic = self.collect(step)
             obs, share_obs, rewards, dones, infos, available_actions = self.envs.step(actions)
             self.insert((obs, share_obs, rewards, dones, infos, available_actions, values, actions, action_log_probs,
                          rnn_states, rnn_states_critic))
         self.compute()
-        return self.train(), infos
+        return infos
+
+    def rollout(self):
+        if not self._use_graph:
+            return self._rollout_body()
+        if self._rollout_graph is None:
+            infos = self._rollout_body()
+            self._rollout_graph = "warm"
+            return infos
+        if self._rollout_graph == "warm":
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._rollout_body()
+            self._rollout_graph = g
+        self._rollout_graph.replay()
+        return None
 
     # smac_runner.py:98-108
     def warmup(self):
@@ -88,6 +114,11 @@ class SMACRunner(Runner):
         obs, share_obs, rewards, dones, infos, available_actions, values, actions, action_log_probs, rnn_states, rnn_states_critic = data
         b = self.buffer
         dev, N, Ma = b.device, b.n_rollout_threads, b.num_agents
+        recurrent = self.trainer._use_recurrent_policy or self.trainer._use_naive_recurrent
+        if (infos is None or isinstance(infos, torch.Tensor)) and b.insert_smac_fused(
+                share_obs if self.use_centralized_V else obs, obs, rewards, dones, infos, available_actions,
+                *((rnn_states, rnn_states_critic) if recurrent else ())):
+            return                                                                           # device env: one kernel did it all
         dones_t = torch.as_tensor(dones).to(dev).view(N, Ma)
         dones_env = dones_t.all(dim=1)                                                       # :132
         keep_env = (~dones_env).to(torch.float32)

@@ -53,6 +53,7 @@ class SharedReplayBuffer(object):
         self.masks = o(T + 1, N, M, 1)
         self.bad_masks = o(T + 1, N, M, 1)
         self.active_masks = o(T + 1, N, M, 1)
+        self.device = self.obs.device                      # with its index ("cuda" -> "cuda:0"): tensors are compared against it
         self.step = 0
 
     # ---- slot writes (shared_buffer.py:79-166) -----------------------------------------------------------
@@ -106,6 +107,37 @@ class SharedReplayBuffer(object):
         if available_actions is not None:
             self._put(self.available_actions[s + 1], available_actions)
         self.step = (s + 1) % self.episode_length
+
+    def insert_smac_fused(self, share_obs, obs, rewards, dones, bad_transition, available_actions, rnn_states=None,
+                          rnn_states_critic=None):
+        """SMAC rollout insert as ONE kernel (mappo_insert_smac; smac_runner.py:129-151): the slot copies plus masks /
+        active_masks / bad_masks / rnn-state resets derived from `dones` [N, M] and `bad_transition` [N, M] (bool, or None).
+        Returns False (nothing written) when the inputs are not device tensors of the expected layout."""
+        dev = self.device
+        f32 = lambda t, d: (torch.is_tensor(t) and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 3
+                            and t.shape[-1] == d)
+        ok = (f32(obs, self.obs.shape[-1]) and f32(share_obs, self.share_obs.shape[-1]) and torch.is_tensor(rewards)
+              and rewards.device == dev and rewards.dtype == torch.float32 and rewards.dim() in (2, 3)
+              and torch.is_tensor(dones) and dones.device == dev and dones.dtype == torch.bool and dones.dim() == 2
+              and (bad_transition is None or (torch.is_tensor(bad_transition) and bad_transition.device == dev
+                                              and bad_transition.dtype == torch.bool and bad_transition.is_contiguous()
+                                              and bad_transition.numel() == dones.numel()))
+              and (available_actions is None or (self.available_actions is not None
+                                                 and f32(available_actions, self.available_actions.shape[-1]))))
+        if rnn_states is not None:
+            state_ok = lambda h: (torch.is_tensor(h) and h.device == dev and h.dtype == torch.float32 and h.is_contiguous()
+                                  and h.numel() == self.rnn_states[0].numel() and h.data_ptr() % 16 == 0)
+            ok = ok and state_ok(rnn_states) and state_ok(rnn_states_critic) and (self.recurrent_N * self.rnn_states.shape[-1]) % 4 == 0
+        if not ok:
+            return False
+        s = self.step
+        ops.insert_smac(obs, share_obs, available_actions, rewards, dones, bad_transition, rnn_states, rnn_states_critic, self.obs[s + 1],
+                        self.share_obs[s + 1], self.available_actions[s + 1] if available_actions is not None else None,
+                        self.rewards[s], self.masks[s + 1], self.bad_masks[s + 1], self.active_masks[s + 1],
+                        self.rnn_states[s + 1] if rnn_states is not None else None,
+                        self.rnn_states_critic[s + 1] if rnn_states is not None else None)
+        self.step = (s + 1) % self.episode_length
+        return True
 
     def insert_mpe_fused(self, obs, rewards, dones, centralized, rnn_states=None, rnn_states_critic=None):
         """MPE rollout insert as ONE kernel (mappo_insert_mpe): obs / share_obs -> slot step+1, rewards -> slot step,

@@ -18,7 +18,7 @@ CONFIGS = {
     "c5": ("mpe5", 400, 256, 64, 512, 512, 5, False, 5, 1, 0.01, 1),      # 2048 threads / 8 GPUs, D_s = 512
 }
 
-def run(name):
+def make_runner(name):
     kind, T, N, M, D, S, A, rec, epochs, nmb, gain, steps = CONFIGS[name]
     a = get_config().parse_known_args([])[0]
     a.algorithm_name = "rmappo" if rec else "mappo"
@@ -35,7 +35,12 @@ def run(name):
         env = SyntheticMPEEnv(N, M, D, A, T, seed=1, device=dev); R = MPERunner
         if kind == "mpe5":
             env.share_observation_space = [[D] for _ in range(M)]
-    r = R(dict(all_args=a, envs=env, eval_envs=None, num_agents=M, device=dev, run_dir=None))
+    return R(dict(all_args=a, envs=env, eval_envs=None, num_agents=M, device=dev, run_dir=None))
+
+
+def run(name):
+    kind, T, N, M, D, S, A, rec, epochs, nmb, gain, steps = CONFIGS[name]
+    r = make_runner(name)
     r.warmup()
     for _ in range(2):
         r.run_episode()
@@ -52,5 +57,6 @@ def run(name):
     del r
     torch.cuda.empty_cache()
 
-for n in (sys.argv[1:] or ["c1", "c2", "c2r", "c3", "c4"]):
-    run(n)
+if __name__ == "__main__":
+    for n in (sys.argv[1:] or ["c1", "c2", "c2r", "c3", "c4"]):
+        run(n)

@@ -266,3 +266,65 @@ def test_wide_observation_train_vs_oracle(M, rec):
         close(v, opol.actor.state_dict()[k].numpy(), 1e-4, 6e-6, k)
     for k, v in pol.critic.state_dict().items():
         close(v, opol.critic.state_dict()[k].numpy(), 1e-4, 6e-6, k)
+
+
+@pytest.mark.parametrize("runner_kind", ["mpe", "smac"])
+def test_recurrent_graph_replay_matches_eager(M, runner_kind):
+    """rmappo iterations replayed as hipGraphs (episode graph + train graph with the chunk permutation drawn on the device)
+    == the same iterations launched eagerly: same seeds, same device random streams, identical parameters afterwards."""
+    from mappo_amd.runner.shared.smac_runner import SMACRunner
+    from mappo_amd.envs.synthetic import SyntheticSMACEnv
+    T, N, Ma, L = 20, 6, 3, 10
+
+    def run(use_graph):
+        torch.manual_seed(5)
+        if runner_kind == "mpe":
+            env, R, D, S, A = M.SyntheticMPEEnv(N, Ma, 18, 5, T, seed=2), M.MPERunner, 18, 54, 5
+        else:
+            env, R = SyntheticSMACEnv(N, Ma, 30, 48, 9, p_death=0.05, p_term=0.1, seed=2), SMACRunner
+        a = make_args(M, episode_length=T, n_rollout_threads=N, ppo_epoch=2, num_mini_batch=1, lr=7e-4, critic_lr=7e-4, seed=1,
+                      env_name="MPE", use_recurrent_policy=True, algorithm_name="rmappo", data_chunk_length=L, use_hip_graph=use_graph)
+        runner = R(dict(all_args=a, envs=env, eval_envs=None, num_agents=Ma, device=torch.device("cuda"), run_dir=None))
+        runner.warmup()
+        infos = [runner.run_episode()[0] for _ in range(4)]          # eager, capture + replay, replay, replay
+        torch.cuda.synchronize()
+        if use_graph:
+            assert isinstance(runner._rollout_graph, torch.cuda.CUDAGraph)
+            assert any(isinstance(g, torch.cuda.CUDAGraph) for g in runner.trainer._graphs.values())
+        return runner.policy.flat_params.clone(), infos
+
+    p_eager, i_eager = run(False)
+    p_graph, i_graph = run(True)
+    np.testing.assert_array_equal(p_graph.cpu().numpy(), p_eager.cpu().numpy())
+    for a, b in zip(i_graph, i_eager):
+        for k in a:
+            assert a[k] == b[k], k
+
+
+@pytest.mark.parametrize("recurrent", [True, False])
+def test_insert_smac_fused_matches_slot_writes(M, recurrent):
+    """mappo_insert_smac (one launch) == smac_runner.py:129-151's mask arithmetic + the slot writes of
+    SharedReplayBuffer.insert (shared_buffer.py:74-112), bit for bit, incl. env terminations, agent deaths and bad transitions."""
+    T, N, Ma, D, S, A, H = 4, 29, 3, 30, 48, 9, 64
+    a = make_args(M, episode_length=T, n_rollout_threads=N, use_recurrent_policy=recurrent, algorithm_name="rmappo" if recurrent else "mappo")
+    b1, b2 = (M.SharedReplayBuffer(a, Ma, [D], [S], M.Discrete(A)) for _ in range(2))
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    for step in range(3):
+        obs, share, avail = rnd(N, Ma, D), rnd(N, Ma, S), (torch.rand(N, Ma, A, device="cuda", generator=g) < 0.7).float()
+        rew = rnd(N, 1, 1).expand(N, Ma, 1)
+        dones = torch.rand(N, Ma, device="cuda", generator=g) < 0.4
+        dones[::5] = True                                                      # terminated envs
+        bad = torch.rand(N, Ma, device="cuda", generator=g) < 0.2
+        ha, hc = rnd(N * Ma, 1, H), rnd(N * Ma, 1, H)
+        assert b1.insert_smac_fused(share, obs, rew, dones, bad, avail, *((ha, hc) if recurrent else ()))
+        dones_env = dones.all(dim=1)
+        keep_env = (~dones_env).float()
+        masks = keep_env.view(N, 1, 1).expand(N, Ma, 1)
+        active = torch.where(dones_env.view(N, 1), torch.ones((), device="cuda"), (~dones).float()).view(N, Ma, 1)
+        k = keep_env.view(N, 1, 1, 1)
+        b2.insert_env(share, obs, rew, masks, ha.view(N, Ma, 1, H) * k if recurrent else None, hc.view(N, Ma, 1, H) * k if recurrent else None,
+                      (~bad).float().view(N, Ma, 1), active, avail)
+    assert b1.step == b2.step
+    for name in ("share_obs", "obs", "rewards", "masks", "bad_masks", "active_masks", "available_actions", "rnn_states", "rnn_states_critic"):
+        np.testing.assert_array_equal(getattr(b1, name).cpu().numpy(), getattr(b2, name).cpu().numpy(), err_msg=name)
