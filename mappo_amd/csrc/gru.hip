@@ -29,7 +29,16 @@
 #define SCR_GHN 4
 #define SCR_HS 5
 
+// Gate nonlinearities on the hardware transcendental units (v_exp_f32 / v_rcp_f32, 1 ulp each): ~5 instructions instead of
+// the ~30 (sigmoid) / ~50 (tanh) of the libm forms — per step and lane the recurrences evaluate 32 + 16 of them back to
+// back.  Absolute error ~1e-7, against the 1e-5 parity bar (tests/test_gpu_gru.py compares every use with the oracle).
+#ifndef GRU_LIBM_GATES
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
+#else
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+#endif
 
 // ---- LDS maps -----------------------------------------------------------------------------------------
 struct GruLds {
@@ -216,7 +225,7 @@ __device__ __forceinline__ void gru_cell(CellOut &c, const float *lds, const Gru
         c.r[t][r] = sigmoidf_(arz[t][r]);
         c.z[t][r] = sigmoidf_(arz[2 + t][r]);
         c.ghn[t][r] = ahn[t][r];
-        c.n[t][r] = tanhf(ain[t][r] + c.r[t][r] * ahn[t][r]);
+        c.n[t][r] = tanhf_(ain[t][r] + c.r[t][r] * ahn[t][r]);
       }
     return;
   }
@@ -268,7 +277,7 @@ __device__ __forceinline__ void gru_cell(CellOut &c, const float *lds, const Gru
       c.r[t][r] = sigmoidf_(arz[t][r]);
       c.z[t][r] = sigmoidf_(arz[2 + t][r]);
       c.ghn[t][r] = ahn[t][r];
-      c.n[t][r] = tanhf(ain[t][r] + c.r[t][r] * ahn[t][r]);
+      c.n[t][r] = tanhf_(ain[t][r] + c.r[t][r] * ahn[t][r]);
     }
 }
 
@@ -711,9 +720,9 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
     load_fm1(gi_r, p.giT, B, cc, w, half);
     load_fm1(gi_z, p.giT + (int64_t)HID * B, B, cc, w, half);
     load_fm1(gi_n, p.giT + (int64_t)2 * HID * B, B, cc, w, half);
+    float mk_next = p.masks[p.rows ? (int64_t)p.rows[cc] : (int64_t)cc];
     for (int t = 0; t < p.L; ++t) {
-      const int64_t col = (int64_t)t * p.Nc + cc;
-      const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[col] : col] : 0.f;
+      const float mk = ok ? mk_next : 0.f;
       float *tH = lds + m.tiles + (t & 1) * m.tile_stride;      // [64][TP] h_{t-1} * mask
       f32x16 hm;
 #pragma unroll
@@ -721,6 +730,7 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
       regs_to_tile1(tH, hm, w, l31, half);
       // next step's input gates: in flight under this step's products (the last step re-reads its own)
       const int64_t ncol = (int64_t)min(t + 1, p.L - 1) * p.Nc + cc;
+      mk_next = p.masks[p.rows ? (int64_t)p.rows[ncol] : ncol];   // rows -> masks: two dependent loads, a step ahead
       f32x16 nx_r, nx_z, nx_n;
       load_fm1(nx_r, p.giT, B, ncol, w, half);
       load_fm1(nx_z, p.giT + (int64_t)HID * B, B, ncol, w, half);
@@ -742,7 +752,7 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
       for (int r = 0; r < 16; ++r) {
         gr[r] = sigmoidf_(ar[r]);
         gz[r] = sigmoidf_(az[r]);
-        gn[r] = tanhf(gi_n[r] + gr[r] * ahn[r]);
+        gn[r] = tanhf_(gi_n[r] + gr[r] * ahn[r]);
         h[r] = (1.f - gz[r]) * gn[r] + gz[r] * hm[r];
       }
       float *base = p.scratch + (int64_t)t * HID * p.Nc;
@@ -904,16 +914,17 @@ __global__ __launch_bounds__(128, 1) void gru_cell_bwd2_kernel(GruBwdArgs p, Seq
       store_fm1(p.dgiT + (int64_t)2 * HID * B, B, col, d_n, ok, w, half);
       store_fm1(p.dghnT, B, col, d_hn, ok, w, half);
       __syncthreads();
-      f32x16 dhm;
+      f32x16 dhm, dhm2;                                  // two independent MFMA chains
 #pragma unroll
-      for (int r = 0; r < 16; ++r) dhm[r] = 0.f;
+      for (int r = 0; r < 16; ++r) { dhm[r] = 0.f; dhm2[r] = 0.f; }
 #pragma unroll 4
-      for (int gg = 0; gg < NG / 2; ++gg) {
+      for (int gg = 0; gg < NG / 2; gg += 2) {
         const int g = 2 * gg + half;
         dhm = mfma(sH[g], tG[g * TP + l31], dhm);
+        dhm2 = mfma(sH[g + 2], tG[(g + 2) * TP + l31], dhm2);
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) carry[r] = (dhm[r] + dh[r] * gz[r]) * mk;
+      for (int r = 0; r < 16; ++r) carry[r] = (dhm[r] + dhm2[r] + dh[r] * gz[r]) * mk;
       dh = n_dh; hm = n_hm; gr = n_r; gz = n_z; gn = n_n; ghn = n_ghn;
       __syncthreads();                                   // both waves are done reading the tile
     }
