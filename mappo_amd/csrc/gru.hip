@@ -658,6 +658,10 @@ __global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
 //                         (h_{t-1} * mask, or the step's d gates); the tile is double-buffered, so one barrier per step.
 // Accumulation orders are those of the one-wave kernels: same values bit for bit (up to the order of the slab sums).
 
+// Workgroup barrier for LDS traffic only.  __syncthreads() also drains the vector-memory queue (s_waitcnt vmcnt(0)): inside the
+// step loops that would wait for the operands prefetched for the NEXT step and for this step's stores — a memory latency per step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct SeqLds { int whh, bhh, tiles, tile_stride, total; };
 __host__ __device__ inline SeqLds seq2_lds(int tile_rows, int n_buf) {
   SeqLds m;
@@ -720,7 +724,12 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
     load_fm1(gi_r, p.giT, B, cc, w, half);
     load_fm1(gi_z, p.giT + (int64_t)HID * B, B, cc, w, half);
     load_fm1(gi_n, p.giT + (int64_t)2 * HID * B, B, cc, w, half);
+    // masks[rows[.]] is a chain of two dependent loads: the row index runs two steps ahead and the mask one, so that no step
+    // waits on a load it has just issued (such a wait would also drain the previous step's stores: vmcnt counts in order)
+    // (the index stays a 32-bit register until it is used: a widening right after the load would wait for it)
     float mk_next = p.masks[p.rows ? (int64_t)p.rows[cc] : (int64_t)cc];
+    int r_next = min(1, p.L - 1) * p.Nc + cc;
+    if (p.rows) r_next = p.rows[r_next];
     for (int t = 0; t < p.L; ++t) {
       const float mk = ok ? mk_next : 0.f;
       float *tH = lds + m.tiles + (t & 1) * m.tile_stride;      // [64][TP] h_{t-1} * mask
@@ -730,12 +739,14 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
       regs_to_tile1(tH, hm, w, l31, half);
       // next step's input gates: in flight under this step's products (the last step re-reads its own)
       const int64_t ncol = (int64_t)min(t + 1, p.L - 1) * p.Nc + cc;
-      mk_next = p.masks[p.rows ? (int64_t)p.rows[ncol] : ncol];   // rows -> masks: two dependent loads, a step ahead
+      mk_next = p.masks[(int64_t)r_next];
+      r_next = min(t + 2, p.L - 1) * p.Nc + cc;
+      if (p.rows) r_next = p.rows[r_next];
       f32x16 nx_r, nx_z, nx_n;
       load_fm1(nx_r, p.giT, B, ncol, w, half);
       load_fm1(nx_z, p.giT + (int64_t)HID * B, B, ncol, w, half);
       load_fm1(nx_n, p.giT + (int64_t)2 * HID * B, B, ncol, w, half);
-      __syncthreads();
+      lds_barrier();
       f32x16 ar, az, ahn = b_n;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { ar[r] = gi_r[r] + b_r[r]; az[r] = gi_z[r] + b_z[r]; }
@@ -880,9 +891,21 @@ __global__ __launch_bounds__(128, 1) void gru_cell_bwd2_kernel(GruBwdArgs p, Seq
       load_fm1(gn, sb + SCR_N * comp, p.Nc, cc, w, half);
       load_fm1(ghn, sb + SCR_GHN * comp, p.Nc, cc, w, half);
     }
+    // masks[rows[.]]: row index two steps ahead, mask one step ahead (see gru_fwd_train2_kernel)
+    float mk_next;
+    int r_next;
+    {
+      const int64_t c0 = (int64_t)(p.L - 1) * p.Nc + cc;
+      mk_next = p.masks[p.rows ? (int64_t)p.rows[c0] : c0];
+      r_next = max(p.L - 2, 0) * p.Nc + cc;
+      if (p.rows) r_next = p.rows[r_next];
+    }
     for (int t = p.L - 1; t >= 0; --t) {
       const int64_t col = (int64_t)t * p.Nc + cc;
-      const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[col] : col] : 0.f;
+      const float mk = ok ? mk_next : 0.f;
+      mk_next = p.masks[(int64_t)r_next];
+      r_next = max(t - 2, 0) * p.Nc + cc;
+      if (p.rows) r_next = p.rows[r_next];
       float *tG = lds + m.tiles;                                // [192][TP] d gh of the step (r, z, n rows), single-buffered
       // the previous step's values: in flight under this step's work (step 0 re-reads its own)
       f32x16 n_dh, n_hm, n_r, n_z, n_n, n_ghn;
@@ -913,7 +936,7 @@ __global__ __launch_bounds__(128, 1) void gru_cell_bwd2_kernel(GruBwdArgs p, Seq
       store_fm1(p.dgiT + (int64_t)HID * B, B, col, d_z, ok, w, half);
       store_fm1(p.dgiT + (int64_t)2 * HID * B, B, col, d_n, ok, w, half);
       store_fm1(p.dghnT, B, col, d_hn, ok, w, half);
-      __syncthreads();
+      lds_barrier();
       f32x16 dhm, dhm2;                                  // two independent MFMA chains
 #pragma unroll
       for (int r = 0; r < 16; ++r) { dhm[r] = 0.f; dhm2[r] = 0.f; }
@@ -926,7 +949,7 @@ __global__ __launch_bounds__(128, 1) void gru_cell_bwd2_kernel(GruBwdArgs p, Seq
 #pragma unroll
       for (int r = 0; r < 16; ++r) carry[r] = (dhm[r] + dhm2[r] + dh[r] * gz[r]) * mk;
       dh = n_dh; hm = n_hm; gr = n_r; gz = n_z; gn = n_n; ghn = n_ghn;
-      __syncthreads();                                   // both waves are done reading the tile
+      lds_barrier();                                     // both waves are done reading the tile
     }
   }
 }
