@@ -88,6 +88,13 @@ int mappo_insert_smac(const float *obs, const float *share_obs, const float *ava
                       float *active_mask_dst, float *rnn_dst, float *rnn_critic_dst, int32_t N, int32_t M, int32_t D, int32_t S,
                       int32_t A, int32_t H, mappo_stream_t stream);
 
+/* recurrent_generator's row indices (shared_buffer.py:385-494) for all ppo epochs of one train() in one launch: perm
+ * [n_epochs][data_chunks] (int64 permutations of the chunks, device), mbs = data_chunks / num_mini_batch;
+ * rows [n_epochs][num_mini_batch][L*mbs] (time-major: l*mbs + j) and h0_rows [n_epochs][num_mini_batch][mbs] are buffer rows
+ * (q % T)*R + q / T of flat position q = chunk*L + l in the reference's (n, m, t) order (T = episode_length, R = N*M). */
+int mappo_recurrent_rows(const int64_t *perm, int32_t n_epochs, int64_t data_chunks, int32_t L, int32_t T, int32_t R,
+                         int32_t num_mini_batch, int32_t *rows, int32_t *h0_rows, mappo_stream_t stream);
+
 /* K1, after_update (shared_buffer.py:114-131): `count` (<= 16) independent fp32 device copies in one launch.
  * dst / src / n_floats are HOST arrays of device pointers / lengths. */
 int mappo_copy_batch(int32_t count, float *const *dst, const float *const *src, const int64_t *n_floats, mappo_stream_t stream);

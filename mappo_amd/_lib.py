@@ -37,6 +37,7 @@ SIGNATURES = {
     "mappo_insert_mpe_rnn": (C.c_int, [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P,
                                        _I32, _P]),
     "mappo_insert_smac": (C.c_int, [_P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _P] + [_P] * 9 + [_I32] * 6 + [_P]),
+    "mappo_recurrent_rows": (C.c_int, [_P, _I32, _I64, _I32, _I32, _I32, _I32, _P, _P, _P]),
     "mappo_copy_batch": (C.c_int, [_I32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(_I64), _P]),
     "mappo_gae_scan": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _F, _F, _I32, _I32, _P]),
     "mappo_adv_workspace_bytes": (_I64, [_I64]),

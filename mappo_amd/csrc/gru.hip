@@ -293,6 +293,7 @@ struct GruFwdArgs {
   const float *masks;         // buffer-order masks, indexed by rows[t*Nc + c] (NULL rows = identity)
   const int32_t *rows;
   int L, Nc, A, head_mode;    // head_mode 0: none, 1: out[B][A], 2: sample (actions/logp [B])
+  int tile_waves;             // waves of a workgroup that own tiles; any further waves only help staging the weights
   float *h_last;              // [Nc][64] row-major or NULL
   float *scratch;             // [6][L][64][Nc] or NULL (training)
   float *out;
@@ -310,10 +311,11 @@ template <bool PRE_GI, int HM>
 __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
   extern __shared__ __align__(16) float lds[];
   const GruLds &m = p.map;
-  const int n_waves = blockDim.x / WAVE;
+  const int n_waves = p.tile_waves;
   const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   stage_gru_all(lds, m, p.params, p.off, p.A, !PRE_GI, HM != 0);
   __syncthreads();
+  if (wave >= n_waves) return;                           // staging helper (no workgroup barrier below)
   float *tHm = lds + m.tiles + wave * m.wave_stride;     // [64][TP] masked previous state (B operand)
   float *tN = tHm + HID * TP;                            // [64][TP] normalised state (head input)   (head modes only)
   float *tZ = tN + HID * TP;                             // [32][TP] head output [s][a]               (head modes only)
@@ -786,7 +788,6 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
 }
 
 // row-local half of the backward over all L x Nc rows; d h' replaces h' in the forward's scratch (component SCR_HS)
-struct HeadLds { GruLds g; int n_waves; };
 #define HEAD_BWD_WAVES 4
 template <int HEAD>
 __global__ __launch_bounds__(WAVE * HEAD_BWD_WAVES, 1) void gru_head_bwd_kernel(GruBwdArgs p, float *dhT) {
@@ -1191,11 +1192,14 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_forward: needs %zu B of LDS", lds_bytes);
   int nb = (n_tiles + nw - 1) / nw;
   if (nb > NUM_CU) nb = NUM_CU;
+  a.tile_waves = nw;
+  // a rollout step (L = 1) is mostly the staging of 98 KB of GRU weights: four waves stage, `nw` of them (LDS budget) own tiles
+  const int launch_waves = 4;
 #define GRU_FWD(PRE, HM_)                                                                                         \
   do {                                                                                                            \
     static bool attr = false;                                                                                     \
     if (!attr) { if (int rc = raise_lds(gru_fwd_kernel<PRE, HM_>, "gru_forward")) return rc; attr = true; }       \
-    hipLaunchKernelGGL((gru_fwd_kernel<PRE, HM_>), dim3(nb), dim3(WAVE * nw), lds_bytes, as_stream(stream), a);   \
+    hipLaunchKernelGGL((gru_fwd_kernel<PRE, HM_>), dim3(nb), dim3(WAVE * launch_waves), lds_bytes, as_stream(stream), a); \
   } while (0)
   if (giT) { if (head_mode == 0) GRU_FWD(true, 0); else if (head_mode == 1) GRU_FWD(true, 1); else GRU_FWD(true, 2); }
   else { if (head_mode == 0) GRU_FWD(false, 0); else if (head_mode == 1) GRU_FWD(false, 1); else GRU_FWD(false, 2); }

@@ -151,6 +151,47 @@ extern "C" int mappo_insert_smac(const float *obs, const float *share_obs, const
   return MAPPO_OK;
 }
 
+// recurrent_generator's index arithmetic (shared_buffer.py:385-494) for ALL ppo epochs of a train() call in one launch.
+// perm[e] is a permutation of the data chunks; minibatch k of epoch e takes chunks c = perm[e][k*mbs + j] and stacks them
+// time-major: flat position q = c*L + l of the reference's (n, m, t) order is buffer row (q % T)*R + q / T.
+struct RecRows {
+  const int64_t *perm;          // [E][chunks]
+  int32_t *rows, *h0;           // [E][nmb][L*mbs], [E][nmb][mbs]
+  int64_t chunks;
+  int E, L, T, R, nmb, mbs;
+};
+__global__ __launch_bounds__(256) void recurrent_rows_kernel(RecRows p) {
+  const int64_t per_e = (int64_t)p.nmb * p.mbs, total = (int64_t)p.E * per_e * p.L;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t j = i % p.mbs;
+    const int l = (int)((i / p.mbs) % p.L);
+    const int64_t ek = i / ((int64_t)p.mbs * p.L);                 // e * nmb + k
+    const int64_t e = ek / p.nmb, k = ek - e * p.nmb;
+    const int64_t c = p.perm[e * p.chunks + k * p.mbs + j];
+    const int64_t q = c * p.L + l;
+    const int32_t row = (int32_t)((q % p.T) * p.R + q / p.T);
+    p.rows[i] = row;                                               // [(e*nmb + k)][l*mbs + j]
+    if (l == 0) p.h0[ek * p.mbs + j] = row;
+  }
+}
+
+extern "C" int mappo_recurrent_rows(const int64_t *perm, int32_t n_epochs, int64_t data_chunks, int32_t L, int32_t T, int32_t R,
+                                    int32_t num_mini_batch, int32_t *rows, int32_t *h0_rows, mappo_stream_t stream) {
+  MAPPO_REQUIRE(perm && rows && h0_rows && n_epochs > 0 && data_chunks > 0 && L > 0 && T > 0 && R > 0 && num_mini_batch > 0,
+                "recurrent_rows: bad arguments");
+  MAPPO_REQUIRE(data_chunks / num_mini_batch > 0, "recurrent_rows: fewer chunks than minibatches");
+  MAPPO_REQUIRE((int64_t)T * R < ((int64_t)1 << 31), "recurrent_rows: buffer rows exceed int32");
+  RecRows a;
+  a.perm = perm; a.rows = rows; a.h0 = h0_rows; a.chunks = data_chunks; a.E = n_epochs; a.L = L; a.T = T; a.R = R;
+  a.nmb = num_mini_batch; a.mbs = (int)(data_chunks / num_mini_batch);
+  const int64_t total = (int64_t)n_epochs * a.nmb * a.mbs * L;
+  int64_t nb = (total + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(recurrent_rows_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), a);
+  MAPPO_CHECK_LAUNCH("recurrent_rows");
+  return MAPPO_OK;
+}
+
 // K1 (after_update, shared_buffer.py:114-131): up to 16 independent device copies in ONE launch (the reference copies
 // slot T of eight arrays back to slot 0; as separate copies each is a launch of a few microseconds).
 #define COPY_MAX 16

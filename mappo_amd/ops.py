@@ -92,6 +92,18 @@ def insert_smac(obs, share_obs, avail, rewards, dones, bad, rnn_states, rnn_stat
     _lib.check(rc, "mappo_insert_smac")
 
 
+def recurrent_rows(perm, L, T, R, num_mini_batch):
+    """perm [E, data_chunks] int64 (device) -> rows [E, nmb, L*mbs], h0_rows [E, nmb, mbs] int32 (mappo_recurrent_rows)."""
+    E, chunks = perm.shape
+    mbs = chunks // num_mini_batch
+    rows = torch.empty(E, num_mini_batch, L * mbs, dtype=torch.int32, device=perm.device)
+    h0 = torch.empty(E, num_mini_batch, mbs, dtype=torch.int32, device=perm.device)
+    rc = _lib.load().mappo_recurrent_rows(_ptr(perm, torch.int64), int(E), int(chunks), int(L), int(T), int(R), int(num_mini_batch),
+                                          _ptr(rows, torch.int32), _ptr(h0, torch.int32), _stream())
+    _lib.check(rc, "mappo_recurrent_rows")
+    return rows, h0
+
+
 def copy_batch(pairs):
     """[(dst, src), ...] contiguous fp32 device tensors of equal numel per pair, copied in ONE launch (<= 16 pairs)."""
     n = len(pairs)

@@ -178,8 +178,14 @@ def train_recurrent(tr, buffer, update_actor=True):
     src = _buffer_sources(tr, buffer, adv)
     T = buffer.episode_length
     tr._acc.zero_()
-    for _ in range(tr.ppo_epoch):
-        if tr._use_recurrent_policy:
+    all_batches = None
+    if tr._use_recurrent_policy and buffer.perm_device != "cpu":
+        all_batches = buffer.recurrent_rows_epochs(tr.ppo_epoch, tr.num_mini_batch, tr.data_chunk_length)   # off the epochs' critical path
+    for epoch in range(tr.ppo_epoch):
+        if all_batches is not None:
+            L = tr.data_chunk_length
+            batches = all_batches[epoch]
+        elif tr._use_recurrent_policy:
             L = tr.data_chunk_length
             batches = buffer.recurrent_rows(tr.num_mini_batch, L)
         else:

@@ -257,6 +257,17 @@ class SharedReplayBuffer(object):
             out.append((rows.to(torch.int32).contiguous(), h0.to(torch.int32).contiguous()))
         return out
 
+    def recurrent_rows_epochs(self, n_epochs, num_mini_batch, data_chunk_length):
+        """`recurrent_rows` for all ppo epochs of a train() call with two random-number launches and ONE index kernel
+        (mappo_recurrent_rows) instead of ~25 small launches per epoch: the epochs' chunk permutations are the argsort of
+        [n_epochs, data_chunks] device uniforms (device permutation stream only — `perm_device="cpu"` keeps the reference's
+        per-epoch torch.randperm).  Returns [[(rows, h0_rows) per minibatch] per epoch]."""
+        T, R = self._dims()
+        data_chunks = (T * R) // data_chunk_length
+        perm = torch.rand(n_epochs, data_chunks, device=self.device).argsort(dim=1)
+        rows, h0 = ops.recurrent_rows(perm, data_chunk_length, T, R, num_mini_batch)
+        return [[(rows[e, k], h0[e, k]) for k in range(num_mini_batch)] for e in range(n_epochs)]
+
     def naive_recurrent_rows(self, num_mini_batch, perm=None):
         """Row indices of `naive_recurrent_generator` (shared_buffer.py:288-383): whole episodes per (n, m)."""
         T, R = self._dims()

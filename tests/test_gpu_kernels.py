@@ -757,3 +757,24 @@ def test_rollout_step_shapes_vs_forward_kernels(ops, Da, Dc, A, LN, relu, fnorm,
     same = (act1 == act0).cpu().numpy()
     assert same.mean() >= 0.98, same.mean()
     np.testing.assert_allclose(lp1.cpu().numpy()[same], lp0.cpu().numpy()[same], rtol=3e-5, atol=3e-6)
+
+
+@pytest.mark.parametrize("T,N,Ma,L,nmb,E", [(25, 16, 3, 10, 1, 3), (20, 6, 3, 10, 2, 2), (400, 8, 5, 10, 4, 2), (7, 5, 2, 3, 1, 1)])
+def test_recurrent_rows_kernel(ops, T, N, Ma, L, nmb, E):
+    """mappo_recurrent_rows (all epochs, one launch) == SharedReplayBuffer.recurrent_rows' index arithmetic
+    (shared_buffer.py:385-494: chunks of the (n, m, t) order, time-major stacking), bit for bit, incl. T % L != 0."""
+    R = N * Ma
+    chunks = (T * R) // L
+    g = torch.Generator(device="cuda").manual_seed(T + L)
+    perm = torch.rand(E, chunks, device="cuda", generator=g).argsort(dim=1)
+    rows, h0 = ops.recurrent_rows(perm, L, T, R, nmb)
+    mbs = chunks // nmb
+    steps = torch.arange(L, device="cuda", dtype=torch.int64)
+    for e in range(E):
+        for k in range(nmb):
+            c = perm[e, k * mbs:(k + 1) * mbs]
+            q = (c[None, :] * L + steps[:, None]).reshape(-1)
+            ref = (q % T) * R + q // T
+            q0 = c * L
+            np.testing.assert_array_equal(rows[e, k].cpu().numpy(), ref.to(torch.int32).cpu().numpy())
+            np.testing.assert_array_equal(h0[e, k].cpu().numpy(), ((q0 % T) * R + q0 // T).to(torch.int32).cpu().numpy())
