@@ -64,6 +64,7 @@ __device__ __forceinline__ void layer16(f32x4 (&out)[NB], const f32x4 (&h)[4], c
 }
 
 // workgroup `bid` of `nb`; MODE 0: out[i] = value (critic, out_dim 1) | MODE 1: sample / argmax + log-prob (actor)
+// | MODE 2: the trunk's output (LayerNorm of the last hidden layer) feature-major, out[64][B] (recurrent networks)
 template <bool RELU, int LN, int MODE>
 __device__ __forceinline__ void forward16_body(const FwdArgs &p, float *lds, const int bid, const int nb) {
   const int n_waves = blockDim.x / WAVE;
@@ -140,7 +141,14 @@ __device__ __forceinline__ void forward16_body(const FwdArgs &p, float *lds, con
       for (int b = 0; b < 4; ++b) h[b] = h2[b];
     }
     // ---- head ----
-    if (MODE == 0) {
+    if (MODE == 2) {
+      if (ok) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p.out[(int64_t)(16 * b + 4 * q + r) * p.B + i] = h[b][r];      // 16 samples x 4 B per segment
+      }
+    } else if (MODE == 0) {
       f32x4 z[1];
       layer16<1>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
       if (ok && q == 0) p.out[i] = z[0][0];                                      // out_dim 1: row a = 0 sits in (q = 0, r = 0)

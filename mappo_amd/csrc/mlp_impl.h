@@ -698,6 +698,13 @@ __global__ __launch_bounds__(256, 1) void rollout_step_kernel(StepArgs s) {
   else insert_mpe_body(s.ins, bid - s.nA - s.nC, s.nI);
 }
 
+// trunk features of a recurrent network (mappo_mlp_features, in_dim <= 64) on the same register-resident 16x16x4 path
+template <bool RELU, int LN>
+__global__ __launch_bounds__(256, 1) void features16_kernel(FwdArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  forward16_body<RELU, LN, 2>(a, lds, blockIdx.x, gridDim.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 // diagnostic build only (-DMLP_STAMPS, scripts/stamps.py): per-phase cycle shares of the update kernel.
 // In the product build STAMP() expands to nothing and no stamp executes.
@@ -1380,7 +1387,44 @@ static int fit_waves(const mappo_net_desc &d, int want) {
 
 #endif
 
+int launch_features16(const FwdArgs &a_in, hipStream_t st);      // defined in the step translation unit
+
 #ifdef MLP_TU_STEP
+template <bool R, int L>
+static int features16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const FwdArgs &a) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)features16_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("mlp_features: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((features16_kernel<R, L>), grid, block, lds_bytes, st, a);
+  return MAPPO_OK;
+}
+
+int launch_features16(const FwdArgs &a_in, hipStream_t st) {
+  MAPPO_CLEAR_STICKY();
+  FwdArgs a = a_in;
+  const int64_t n_tiles = (a.B + 15) / 16;
+  const int nw = fit_waves(a.desc, n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1));
+  a.off = net_offsets(a.desc); a.map = lds_map(a.desc, nw);
+  const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "mlp_features: needs %zu B of LDS", lds_bytes);
+  int64_t nb = (n_tiles + nw - 1) / nw;
+  if (nb > 2 * NUM_CU) nb = 2 * NUM_CU;                      // every workgroup stages the weights once, then walks its tiles
+  dim3 grid((unsigned)nb), block(WAVE * nw);
+  const bool relu = a.desc.use_relu != 0;
+  int rc;
+  switch (a.desc.layer_N) {
+    case 0: rc = relu ? features16_launch<true, 0>(grid, block, lds_bytes, st, a) : features16_launch<false, 0>(grid, block, lds_bytes, st, a); break;
+    case 1: rc = relu ? features16_launch<true, 1>(grid, block, lds_bytes, st, a) : features16_launch<false, 1>(grid, block, lds_bytes, st, a); break;
+    default: rc = relu ? features16_launch<true, 2>(grid, block, lds_bytes, st, a) : features16_launch<false, 2>(grid, block, lds_bytes, st, a); break;
+  }
+  if (rc) return rc;
+  MAPPO_CHECK_LAUNCH("mlp_features");
+  return MAPPO_OK;
+}
+
 // ---- fused rollout step (rollout_step_kernel): translation unit mlp_step.hip --------------------------------------
 template <bool R, int L>
 static int step_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const StepArgs &a) {
@@ -1512,6 +1556,7 @@ extern "C" int mappo_mlp_features(const float *params, const mappo_net_desc *des
   MAPPO_REQUIRE(params && x && featT && B > 0, "mlp_features: bad arguments");
   FwdArgs a = {};
   a.params = params; a.x = x; a.rows = rows; a.out = featT; a.desc = *desc; a.B = B;
+  if (desc->in_dim <= MAXD) return launch_features16(a, as_stream(stream));
   return launch_forward<2>(a, as_stream(stream), "mlp_features");
 }
 
