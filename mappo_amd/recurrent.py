@@ -89,19 +89,28 @@ def critic_forward(critic, cent_obs, rnn_states, masks, values):
 
 
 # ---- training -------------------------------------------------------------------------------------------------------
-def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
-    """One PPO update on `Nc` sequences of `L` steps (r_mappo.py:91-164 with the recurrent evaluate_actions)."""
+def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
+    """One PPO update on `Nc` sequences of `L` steps (r_mappo.py:91-164 with the recurrent evaluate_actions).
+    `epochs` = (e, n, states[n, 3]): the minibatch is the same set of rows in every one of the n ppo epochs (num_mini_batch
+    == 1: every permutation of the chunks covers the same rows), so epoch 0 takes the batch moments and performs all n
+    ValueNorm updates in one launch (mappo_valuenorm_update_n) and update e normalises with states[e]."""
     pol = tr.policy
     B = L * Nc
     lib = ops._lib.load()
     dev = tr.device
     vn_state = tr.value_normalizer.state if tr._use_valuenorm else None
-    ops.minibatch_moments(src["returns"], src["active"], rows, B, tr._mb_moments,
-                          tr._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
-    if tr._dist is not None:
-        tr._dist.all_reduce_sum_(tr._mb_moments)
-    if tr._use_valuenorm:
-        ops.valuenorm_update(vn_state, tr._mb_moments, tr.value_normalizer.beta)
+    if epochs is None or epochs[0] == 0:
+        ops.minibatch_moments(src["returns"], src["active"], rows, B, tr._mb_moments,
+                              tr._bytes("mom_ws", lib.mappo_moments_workspace_bytes(B)))
+        if tr._dist is not None:
+            tr._dist.all_reduce_sum_(tr._mb_moments)
+        if tr._use_valuenorm:
+            if epochs is None:
+                ops.valuenorm_update(vn_state, tr._mb_moments, tr.value_normalizer.beta)
+            else:
+                ops.valuenorm_update_n(vn_state, tr._mb_moments, tr.value_normalizer.beta, epochs[1], epochs[2])
+    if epochs is not None and tr._use_valuenorm:
+        vn_state = epochs[2][epochs[0]]
     n_trunk, n_bwd, n_wg = ops.mlp_backward_slabs(B), ops.gru_backward_slabs(Nc), ops.gru_wgrad_slabs(L, Nc)
     n_slabs = max(n_trunk, n_bwd, n_wg)
     P = pol.n_flat
@@ -148,12 +157,15 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor):
     else:
         one_net(*nets[0])
     ops.update_stats(pa if update_actor else None, n_bwd, pc, n_bwd, tr._mb_moments, tr._cfg, tr._stats, tr._acc)
-    ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
-    if tr._dist is not None:
-        tr._dist.all_reduce_sum_(pol.flat_grad)
     if update_actor != tr._actor_enabled:
         pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
         tr._actor_enabled = update_actor
+    if tr._dist is None:                   # single process: reduction + clip + Adam in two launches
+        ops.reduce_clip_adam(slabs, n_slabs, P, pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds,
+                             pol.opt_hyper, pol.opt_step, pol.grad_norms, pol.opt_workspace, norm_acc=tr._acc[4:])
+        return
+    ops.slab_reduce(slabs, n_slabs, P, P, pol.flat_grad)
+    tr._dist.all_reduce_sum_(pol.flat_grad)
     ops.clip_adam(pol.flat_params, pol.flat_grad, pol.exp_avg, pol.exp_avg_sq, pol.seg_bounds, pol.opt_hyper, pol.opt_step,
                   pol.grad_norms, pol.opt_workspace, norm_acc=tr._acc[4:])
 
@@ -191,8 +203,9 @@ def train_recurrent(tr, buffer, update_actor=True):
         else:
             L = T
             batches = buffer.naive_recurrent_rows(tr.num_mini_batch)
+        ep = (epoch, tr.ppo_epoch, tr._buf("vn_states", (tr.ppo_epoch, 3))) if tr.num_mini_batch == 1 else None
         for rows, h0_rows in batches:
-            _update_recurrent(tr, src, rows, h0_rows, L, h0_rows.numel(), update_actor)
+            _update_recurrent(tr, src, rows, h0_rows, L, h0_rows.numel(), update_actor, ep)
 
 
 def ppo_update_recurrent(tr, sample, update_actor=True):
