@@ -328,3 +328,28 @@ def test_insert_smac_fused_matches_slot_writes(M, recurrent):
     assert b1.step == b2.step
     for name in ("share_obs", "obs", "rewards", "masks", "bad_masks", "active_masks", "available_actions", "rnn_states", "rnn_states_critic"):
         np.testing.assert_array_equal(getattr(b1, name).cpu().numpy(), getattr(b2, name).cpu().numpy(), err_msg=name)
+
+
+def test_recurrent_rows_epochs_are_permutations(M):
+    """recurrent_rows_epochs: every epoch's minibatches together visit each chunk exactly once (a permutation of the chunks
+    per epoch, different between epochs), and the rows of a chunk are L consecutive positions of the (n, m, t) order."""
+    T, N, Ma, L, nmb, E = 25, 8, 3, 10, 2, 4
+    a = make_args(M, episode_length=T, n_rollout_threads=N, use_recurrent_policy=True, algorithm_name="rmappo", data_chunk_length=L,
+                  num_mini_batch=nmb)
+    b = M.SharedReplayBuffer(a, Ma, [18], [54], M.Discrete(5))
+    R = N * Ma
+    chunks = (T * R) // L
+    out = b.recurrent_rows_epochs(E, nmb, L)
+    assert len(out) == E and all(len(o) == nmb for o in out)
+    firsts = []
+    for ep in out:
+        h0 = torch.cat([h for _, h in ep]).cpu().numpy().astype(np.int64)
+        q0 = (h0 % R) * T + h0 // R                                  # buffer row t*R + r  ->  flat position r*T + t
+        assert sorted(q0.tolist()) == [c * L for c in range(chunks)]             # chunks % nmb == 0 here: all of them, once
+        firsts.append(q0[:16].tolist())
+        for rows, h in ep:
+            r = rows.cpu().numpy().astype(np.int64).reshape(L, -1)
+            q = (r % R) * T + r // R
+            np.testing.assert_array_equal(q, q[0][None, :] + np.arange(L)[:, None])
+            np.testing.assert_array_equal(r[0], h.cpu().numpy())
+    assert len({tuple(f) for f in firsts}) == E                      # epochs differ
