@@ -266,10 +266,10 @@ int mappo_mlp_features(const float *params, const mappo_net_desc *desc /*host*/,
 int64_t mappo_gru_scratch_floats(int32_t L, int32_t Nc);
 /* Input-side products of the GRU, outside the sequential kernels (no time dependence: plain row-tile products over all
  * B = L*Nc rows):  giT [192][B] = W_ih featT + b_ih   and   dxT [64][B] = W_ih^T dgiT.  mappo_gru_forward with giT != NULL
- * and mappo_gru_backward with dxT == NULL then carry only the W_hh half of the matrix work.  That is the training
- * configuration, and there both run with two waves per 32 sequences (one per half of the hidden features), and
- * mappo_gru_backward becomes two launches: the row-local half (rnn.norm, head, PPO loss and their backward) over all B rows
- * at once, which OVERWRITES the h' component of `scratch` with d h', then the recurrence proper. */
+ * then carries only the W_hh half of the matrix work, with two waves per 32 sequences (one per half of the hidden
+ * features).  mappo_gru_backward is two launches: the row-local half (rnn.norm, head, PPO loss and their backward) over all
+ * B rows at once, which OVERWRITES the h' component of `scratch` with d h', then the recurrence proper (same two-wave
+ * form); with dxT != NULL it finishes with mappo_gru_input_backward(dgiT -> dxT). */
 int mappo_gru_input_gates(const float *params, const mappo_net_desc *desc /*host*/, const float *featT /*[64][B]*/, int64_t B,
                           float *giT /*[192][B]*/, mappo_stream_t stream);
 int mappo_gru_input_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *dgiT /*[192][B]*/, int64_t B,

@@ -11,12 +11,15 @@
 // All per-step scratch between the kernels is FEATURE-MAJOR ([feature][row], row = t*Nc + c), so accumulator-layout
 // registers are loaded/stored as coalesced 128-B segments and MFMA B operands can be read straight from HBM/L2.
 //
-//   gru_fwd_kernel   x_T[64][B], h0 -> h_t for t < L; optional per-step head output / action sampling (rollout,
-//                    get_values, evaluate) ; in training mode stores hm, r, z, n, gh_n, h' per step
-//   gru_bwd_kernel   reverse time: LayerNorm + head + in-kernel PPO loss (actor | critic) at step t, cell backward,
-//                    dx_t = W_ih^T dgi, carry = (W_hh^T dgh + dh*z) * mask ; writes dx_T, dgi_T, dghn_T,
-//                    head / rnn.norm gradient slabs and loss partial sums
-//   gru_wgrad_kernel dW_ih, dW_hh, db_ih, db_hh = row-tile GEMMs over (dgi, x) and (dgh, hm) -> slabs
+//   gru_fwd_kernel        x_T[64][B], h0 -> h_t for t < L; optional per-step head output / action sampling (rollout,
+//                         get_values, evaluate); with scratch stores hm, r, z, n, gh_n, h' per step
+//   gru_gi_kernel / gru_dx_kernel   the input-side products W_ih x + b_ih and W_ih^T dgi over all rows (no time dependence)
+//   gru_fwd_train2_kernel the training forward recurrence on precomputed input gates, two waves per 32 sequences
+//   gru_head_bwd_kernel   LayerNorm + head + in-kernel PPO loss (actor | critic) and their backward over all rows:
+//                         d h'_t without the recurrent term, head / rnn.norm gradient slabs, loss partial sums
+//   gru_cell_bwd2_kernel  reverse time, two waves per 32 sequences: cell backward, carry = (W_hh^T dgh + dh*z) * mask;
+//                         writes dgi_T, dghn_T
+//   gru_wgrad_kernel      dW_ih, dW_hh, db_ih, db_hh = row-tile GEMMs over (dgi, x) and (dgh, hm) -> slabs
 #include "mlp_core.h"
 
 #define GS 193              // LDS row stride of the GRU weights (k-major: sW[k*GS + g], g < 192)
@@ -507,144 +510,6 @@ __device__ __forceinline__ void gru_head_backward(f32x16 (&dh)[2], const GruBwdA
   for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dh[tt][r] = rstd * (dH[tt][r] - m1 - xh[tt][r] * m2);
-}
-
-// HEAD 1 actor | 2 critic loss; DX: compute d x in the kernel (false: deferred to gru_dx_kernel) — compile-time, see gru_fwd_kernel
-template <int HEAD, bool DX>
-__global__ __launch_bounds__(64, 1) void gru_bwd_kernel(GruBwdArgs p) {
-  extern __shared__ __align__(16) float lds[];
-  __shared__ double red_smem[16 * 4];
-  const GruLds &m = p.map;
-  const NetOff &o = p.off;
-  const int lane = threadIdx.x, l31 = lane & 31, half = lane >> 5;
-  const int A = p.A;
-  stage_gru_all(lds, m, p.params, o, A, DX, true);
-  __syncthreads();
-  float *tG = lds + m.tiles;                 // [192][TP]  d gi / d gh (B operand of the W^T products)
-  float *tN = tG + NG * TP;                  // [64][TP]   normalised state, then scratch
-  float *tZ = tN + HID * TP;                 // [32][TP]   head output / gradient [s][a]
-  const int64_t B = (int64_t)p.L * p.Nc;
-  const int64_t comp = (int64_t)p.L * HID * p.Nc;
-  const LossScales ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
-  double lacc[4] = {0.0, 0.0, 0.0, 0.0};
-  f32x16 gWh[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gWh[i][r] = 0.f;
-  float gBh = 0.f, gNw = 0.f, gNb = 0.f;
-
-  const int n_tiles = (p.Nc + TS - 1) / TS;
-  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int c = tile * TS + l31;
-    const bool ok = c < p.Nc;
-    f32x16 carry[2];
-#pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) carry[tt][r] = 0.f;
-    for (int t = p.L - 1; t >= 0; --t) {
-      const int64_t col = (int64_t)t * p.Nc + c;
-      const float *sb = p.scratch + (int64_t)t * HID * p.Nc;
-      const int64_t brow = ok ? (p.rows ? (int64_t)p.rows[col] : col) : 0;
-      f32x16 dh[2];
-      gru_head_backward<HEAD>(dh, p, lds, m, tN, tZ, ls, sb + SCR_HS * comp, c, ok, brow, lane, l31, half, gWh, gBh, gNw, gNb, lacc);
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dh[tt][r] += carry[tt][r];
-      // ---- cell backward ----
-      f32x16 hm[2], gr[2], gz[2], gn[2], ghn[2];
-      load_fm(hm, sb + SCR_HM * comp, p.Nc, c, ok, half);
-      load_fm(gr, sb + SCR_R * comp, p.Nc, c, ok, half);
-      load_fm(gz, sb + SCR_Z * comp, p.Nc, c, ok, half);
-      load_fm(gn, sb + SCR_N * comp, p.Nc, c, ok, half);
-      load_fm(ghn, sb + SCR_GHN * comp, p.Nc, c, ok, half);
-      f32x16 d_r[2], d_z[2], d_n[2], d_hn[2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float dhh = dh[tt][r], zz = gz[tt][r], nn = gn[tt][r], rr = gr[tt][r];
-          const float dn_pre = dhh * (1.f - zz) * (1.f - nn * nn);
-          d_n[tt][r] = dn_pre;
-          d_hn[tt][r] = dn_pre * rr;
-          d_r[tt][r] = dn_pre * ghn[tt][r] * rr * (1.f - rr);
-          d_z[tt][r] = dhh * (hm[tt][r] - nn) * zz * (1.f - zz);
-        }
-      // scratch for the weight-gradient GEMMs
-      store_fm(p.dgiT, B, col, d_r, ok, half);
-      store_fm(p.dgiT + (int64_t)HID * B, B, col, d_z, ok, half);
-      store_fm(p.dgiT + (int64_t)2 * HID * B, B, col, d_n, ok, half);
-      store_fm(p.dghnT, B, col, d_hn, ok, half);
-      // tG <- d gi  [g][s]
-      regs_to_tile64(tG, d_r, l31, half);
-      regs_to_tile64(tG + HID * TP, d_z, l31, half);
-      if (DX) {                                 // d x_t = W_ih^T . d gi here; otherwise deferred to mappo_gru_input_backward
-        regs_to_tile64(tG + 2 * HID * TP, d_n, l31, half);
-        wave_lds_sync();
-        f32x16 dx[2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) dx[tt][r] = 0.f;
-        {
-          const float *sI = lds + m.wih;
-#pragma unroll 4
-          for (int gg = 0; gg < NG / 2; ++gg) {
-            const int g = 2 * gg + half;
-            const float b = tG[g * TP + l31];
-            dx[0] = mfma(sI[l31 * GS + g], b, dx[0]);
-            dx[1] = mfma(sI[(32 + l31) * GS + g], b, dx[1]);
-          }
-        }
-        store_fm(p.dxT, B, col, dx, ok, half);
-        wave_lds_sync();
-      }
-      // tG n-rows <- d gh_n ; d hm = W_hh^T . d gh
-      regs_to_tile64(tG + 2 * HID * TP, d_hn, l31, half);
-      wave_lds_sync();
-      f32x16 dhm[2];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dhm[tt][r] = 0.f;
-      {
-        const float *sH = lds + m.whh;
-#pragma unroll 4
-        for (int gg = 0; gg < NG / 2; ++gg) {
-          const int g = 2 * gg + half;
-          const float b = tG[g * TP + l31];
-          dhm[0] = mfma(sH[l31 * GS + g], b, dhm[0]);
-          dhm[1] = mfma(sH[(32 + l31) * GS + g], b, dhm[1]);
-        }
-      }
-      float mk = 0.f;
-      if (ok) mk = p.masks[brow];
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) carry[tt][r] = (dhm[tt][r] + dh[tt][r] * gz[tt][r]) * mk;
-      wave_lds_sync();
-    }
-  }
-  // ---- loss partial sums + this workgroup's slab (head and rnn.norm columns only) ----
-  block_sum<4>(lacc, red_smem);
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) p.partials[(size_t)blockIdx.x * 4 + k] = lacc[k];
-  }
-  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
-#pragma unroll
-  for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int a = ROWMAP(r, half);
-      if (a < A) slab[o.wh + a * HID + 32 * tj + l31] = gWh[tj][r];
-    }
-  if (half == 0 && l31 < A) slab[o.bh + l31] = gBh;
-  slab[o.rn_w + lane] = gNw;
-  slab[o.rn_b + lane] = gNb;
 }
 
 // ---- training path, split three ways -------------------------------------------------------------------
@@ -1208,6 +1073,9 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   return MAPPO_OK;
 }
 
+static int launch_gru_in(bool gates, const float *params, const mappo_net_desc *desc, const float *inT, int64_t B, float *outT,
+                         hipStream_t st, const char *who);
+
 extern "C" int32_t mappo_gru_backward_slabs(int32_t Nc) {
   const int n_tiles = (Nc + TS - 1) / TS;
   return n_tiles < NUM_CU ? n_tiles : NUM_CU;
@@ -1233,8 +1101,8 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
   a.dghnT = dghnT; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0; a.partials = partials;
   MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru_backward: slab column range");
   const int nb = mappo_gru_backward_slabs(Nc);
-  if (!dxT) {
-    // training: the row-local half over all L x Nc rows (d h' replaces h' in the forward's scratch), then the recurrence
+  {
+    // the row-local half over all L x Nc rows (d h' replaces h' in the forward's scratch), then the recurrence
     const int n_ct = (Nc + TS - 1) / TS;
     const int64_t n_tiles = (int64_t)L * n_ct;
     int nw = (int)((n_tiles + nb - 1) / nb);
@@ -1269,20 +1137,8 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
     if (!attr2) { if (int rc = raise_lds(gru_cell_bwd2_kernel, "gru_backward")) return rc; attr2 = true; }
     hipLaunchKernelGGL(gru_cell_bwd2_kernel, dim3(n_ct < 4 * NUM_CU ? n_ct : 4 * NUM_CU), dim3(2 * WAVE), sbytes, as_stream(stream), a, sm);
     MAPPO_CHECK_LAUNCH("gru_backward (cell)");
-    return MAPPO_OK;
   }
-  a.map = gru_lds(1, NG + HID + TS, true);
-  const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
-  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "gru_backward: needs %zu B of LDS", lds_bytes);
-#define GRU_BWD(H_, DX_)                                                                                          \
-  do {                                                                                                            \
-    static bool attr = false;                                                                                     \
-    if (!attr) { if (int rc = raise_lds(gru_bwd_kernel<H_, DX_>, "gru_backward")) return rc; attr = true; }       \
-    hipLaunchKernelGGL((gru_bwd_kernel<H_, DX_>), dim3(nb), dim3(WAVE), lds_bytes, as_stream(stream), a);         \
-  } while (0)
-  if (head == 1) GRU_BWD(1, true); else GRU_BWD(2, true);
-#undef GRU_BWD
-  MAPPO_CHECK_LAUNCH("gru_backward");
+  if (dxT) return launch_gru_in(false, params, desc, dgiT, (int64_t)L * Nc, dxT, as_stream(stream), "gru_backward");   // d x = W_ih^T d gi
   return MAPPO_OK;
 }
 

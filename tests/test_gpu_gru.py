@@ -353,3 +353,46 @@ def test_recurrent_rows_epochs_are_permutations(M):
             np.testing.assert_array_equal(q, q[0][None, :] + np.arange(L)[:, None])
             np.testing.assert_array_equal(r[0], h.cpu().numpy())
     assert len({tuple(f) for f in firsts}) == E                      # epochs differ
+
+
+def test_gru_backward_with_dx_matches_deferred_input_backward(M):
+    """mappo_gru_backward(dxT != NULL) == mappo_gru_backward(dxT = NULL) followed by mappo_gru_input_backward, bit for bit
+    (same kernels; the call only appends the W_ih^T product), on a forward pass without / with precomputed input gates."""
+    from mappo_amd import ops
+    a = make_args(M, use_recurrent_policy=True, algorithm_name="rmappo")
+    pol = M.R_MAPPOPolicy(a, [18], [54], M.Discrete(5))
+    tr = M.R_MAPPO(a, pol)
+    net, L, Nc, H = pol.critic, 5, 70, 64
+    B = L * Nc
+    g = torch.Generator(device="cuda").manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    featT, h0 = rnd(H, B), rnd(Nc, H)
+    masks = (torch.rand(B, device="cuda", generator=g) > 0.2).float()
+    active, v_old, ret = torch.ones(B, device="cuda"), rnd(B), rnd(B)
+    tr._mb_moments.copy_(torch.tensor([float(ret.sum()), float((ret * ret).sum()), float(B), float(B)], dtype=torch.float64))
+    vn = torch.tensor([0.1, 1.3, 0.9], device="cuda")
+    P = pol.n_flat
+    n_slabs = ops.gru_backward_slabs(Nc)
+    outs = []
+    for pre_gi in (False, True):
+        for with_dx in (True, False):
+            scratch = torch.empty(ops.gru_scratch_floats(L, Nc), device="cuda")
+            giT = torch.empty(3 * H, B, device="cuda") if pre_gi else None
+            if pre_gi:
+                ops.gru_input_gates(net.flat, net.desc, featT, B, giT)
+            ops.gru_forward(net.flat, net.desc, featT, h0, None, masks, None, L, Nc, scratch=scratch, head_mode=0, giT=giT)
+            dxT, dgiT, dghnT = torch.zeros(H, B, device="cuda"), torch.empty(3 * H, B, device="cuda"), torch.empty(H, B, device="cuda")
+            slabs = torch.zeros(n_slabs, P, device="cuda")
+            part = torch.zeros(4 * n_slabs, dtype=torch.float64, device="cuda")
+            ops.gru_backward(net.flat, net.desc, scratch, masks, None, L, Nc, 2, None, None, None, None, active, v_old, ret, vn,
+                             tr._mb_moments, tr._cfg, dxT if with_dx else None, dgiT, dghnT, slabs, P, pol.seg_bounds[1], part)
+            if not with_dx:
+                ops.gru_input_backward(net.flat, net.desc, dgiT, B, dxT)
+            outs.append([t.cpu().numpy() for t in (dxT, dgiT, dghnT, slabs, part)])
+    assert np.abs(outs[0][0]).max() > 0
+    for other in outs[1:]:
+        for x, y in zip(outs[0][:3], other[:3]):
+            np.testing.assert_allclose(y, x, rtol=2e-5, atol=2e-6)          # in-kernel vs precomputed W_ih x: summation order
+    for k in (0, 2):
+        for x, y in zip(outs[k], outs[k + 1]):
+            np.testing.assert_array_equal(y, x)                             # with / without dxT: identical
