@@ -652,6 +652,143 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
   }
 }
 
+// One rollout / evaluation step (L = 1) with head, two waves per 32 rows: wave w computes the gates of hidden features
+// [32 w, 32 w + 32) from x (B operand straight from feature-major HBM) and h * mask (LDS tile written by both waves) — 192 of
+// the step's 384 MFMAs, in six independent chains.  LayerNorm(64) joins the two halves' (mean, M2) (Chan); the head is split
+// over k (each wave its own 32 normalised features), wave 0 adds the partner's partial logits and samples / writes the output.
+#define STEP2_PAIR_FLOATS (HID * TP + 3 * TS * TP + 128)     // tHm (later the partial-logit exchange) | tN x 2 | tZ | LN stats
+template <int HM>
+__global__ __launch_bounds__(256, 1) void gru_step2_kernel(GruFwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  const GruLds &m = p.map;
+  const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
+  const int pair = wv >> 1, w = wv & 1;
+  stage_gru_all(lds, m, p.params, p.off, p.A, true, true);
+  __syncthreads();
+  float *pb = lds + m.tiles + pair * STEP2_PAIR_FLOATS;
+  float *tHm = pb, *tX = pb;                              // [64][TP] h * mask ; after the products: [16][64] partial logits of wave 1
+  float *tN = pb + HID * TP + w * TS * TP;                // [32][TP] this wave's normalised features (B operand of the head)
+  float *tZ = pb + HID * TP + 2 * TS * TP;                // [32][TP] logits [s][a]
+  float *st = tZ + TS * TP;                               // [2][2][32] LayerNorm partial statistics
+  const int64_t B = p.Nc;                                 // L == 1: column = sequence
+  const int n_tiles = (p.Nc + TS - 1) / TS;
+  const float *sI = lds + m.wih + 32 * w + l31, *sH = lds + m.whh + 32 * w + l31;
+  for (int t0 = blockIdx.x * 2; t0 < n_tiles; t0 += gridDim.x * 2) {        // both pairs make every trip (workgroup barriers inside)
+    const int tile = t0 + pair;
+    const int c = tile * TS + l31;
+    const bool ok = tile < n_tiles && c < p.Nc;
+    const int cc = ok ? c : 0;
+    const int n_valid = tile < n_tiles ? min(TS, p.Nc - tile * TS) : 0;
+    const int64_t hrow = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
+    const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[cc] : (int64_t)cc] : 0.f;
+    float bx[HID / 2];
+#pragma unroll
+    for (int kk = 0; kk < HID / 2; ++kk) bx[kk] = p.xT[(int64_t)(2 * kk + half) * B + cc];
+    f32x16 hm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4 *>(p.h0 + hrow * HID + 32 * w + 8 * q + 4 * half);
+      hm[4 * q + 0] = v.x * mk; hm[4 * q + 1] = v.y * mk; hm[4 * q + 2] = v.z * mk; hm[4 * q + 3] = v.w * mk;
+    }
+    regs_to_tile1(tHm, hm, w, l31, half);
+    f32x16 ar, az, ain, ahn;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int f = 32 * w + ROWMAP(r, half);
+      ar[r] = lds[m.bih + f] + lds[m.bhh + f];
+      az[r] = lds[m.bih + HID + f] + lds[m.bhh + HID + f];
+      ain[r] = lds[m.bih + 2 * HID + f];
+      ahn[r] = lds[m.bhh + 2 * HID + f];
+    }
+    lds_barrier();
+#pragma unroll 4
+    for (int kk = 0; kk < HID / 2; ++kk) {
+      const int k = 2 * kk + half;
+      const float bxx = ok ? bx[kk] : 0.f, bh = tHm[k * TP + l31];
+      ar = mfma(sI[k * GS], bxx, ar);
+      az = mfma(sI[k * GS + HID], bxx, az);
+      ain = mfma(sI[k * GS + 2 * HID], bxx, ain);
+      ar = mfma(sH[k * GS], bh, ar);
+      az = mfma(sH[k * GS + HID], bh, az);
+      ahn = mfma(sH[k * GS + 2 * HID], bh, ahn);
+    }
+    f32x16 h;
+    float s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float gr = sigmoidf_(ar[r]), gz = sigmoidf_(az[r]);
+      const float gn = tanhf_(ain[r] + gr * ahn[r]);
+      h[r] = (1.f - gz) * gn + gz * hm[r];
+      s1 += h[r];
+    }
+    if (p.h_last && ok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<float4 *>(p.h_last + (int64_t)c * HID + 32 * w + 8 * q + 4 * half) =
+            make_float4(h[4 * q + 0], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+    }
+    // ---- LayerNorm(64): this wave's (mean, M2) over its 32 features, joined with the partner's ----
+    const float mean_w = xhalf_sum(s1) * (1.f / 32.f);
+    float q2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { const float d = h[r] - mean_w; q2 += d * d; }
+    q2 = xhalf_sum(q2);
+    if (half == 0) { st[w * 64 + l31] = mean_w; st[w * 64 + 32 + l31] = q2; }
+    lds_barrier();
+    const float mean_o = st[(1 - w) * 64 + l31], q2_o = st[(1 - w) * 64 + 32 + l31];
+    const float mean = 0.5f * (mean_w + mean_o), dm = mean_w - mean_o;
+    const float rstd = 1.0f / sqrtf((q2 + q2_o + dm * dm * 16.f) * (1.f / HID) + LN_EPS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int fl = ROWMAP(r, half);
+      tN[fl * TP + l31] = (h[r] - mean) * rstd * lds[m.nw + 32 * w + fl] + lds[m.nb + 32 * w + fl];
+    }
+    wave_lds_sync();
+    // ---- head, split over k: partial logits of this wave's 32 features ----
+    f32x16 z;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4 *>(lds + m.bh + 8 * q + 4 * half);
+      z[4 * q + 0] = w == 0 ? b.x : 0.f; z[4 * q + 1] = w == 0 ? b.y : 0.f; z[4 * q + 2] = w == 0 ? b.z : 0.f; z[4 * q + 3] = w == 0 ? b.w : 0.f;
+    }
+    {
+      const float *sW = lds + m.wh + 32 * w * HP;
+#pragma unroll 8
+      for (int kk = 0; kk < TS / 2; ++kk) {
+        const int kl = 2 * kk + half;
+        z = mfma(sW[kl * HP + l31], tN[kl * TP + l31], z);
+      }
+    }
+    if (w == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tX[r * WAVE + lane] = z[r];
+    }
+    lds_barrier();
+    if (w == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] += tX[r * WAVE + lane];
+      head_to_tile(tZ, z, p.A, l31, half);
+      wave_lds_sync();
+      const int64_t row0 = (int64_t)tile * TS;
+      if (HM == 1) {
+        for (int e = lane; e < n_valid * p.A; e += WAVE) {
+          const int sidx = e / p.A, a = e - sidx * p.A;
+          p.out[row0 * p.A + e] = tZ[sidx * TP + a];
+        }
+      } else if (lane < n_valid) {
+        const int64_t i = row0 + lane;
+        const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+        float action, logp;
+        categorical_act_lane(tZ + lane * TP, p.A, p.avail ? p.avail + i * p.A : nullptr, p.deterministic != 0, p.seed, ctr, (uint64_t)i,
+                             action, logp);
+        p.actions[i] = action;
+        p.logp[i] = logp;
+      }
+    }
+    lds_barrier();                                        // the tiles are rewritten by the next trip
+  }
+}
+
 // row-local half of the backward over all L x Nc rows; d h' replaces h' in the forward's scratch (component SCR_HS)
 #define HEAD_BWD_WAVES 4
 template <int HEAD>
@@ -1046,6 +1183,24 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
     static bool attr2 = false;
     if (!attr2) { if (int rc = raise_lds(gru_fwd_train2_kernel, "gru_forward")) return rc; attr2 = true; }
     hipLaunchKernelGGL(gru_fwd_train2_kernel, dim3(n_tiles < 4 * NUM_CU ? n_tiles : 4 * NUM_CU), dim3(2 * WAVE), bytes, as_stream(stream), a, sm);
+    MAPPO_CHECK_LAUNCH("gru_forward");
+    return MAPPO_OK;
+  }
+  if (!giT && !scratch && L == 1 && head_mode != 0) {       // rollout / get_values step: two waves per 32 rows
+    a.map = gru_lds(0, 0, true);
+    const size_t bytes = (size_t)(a.map.total + 2 * STEP2_PAIR_FLOATS) * sizeof(float);
+    MAPPO_REQUIRE(bytes <= LDS_DYN_MAX, "gru_forward: needs %zu B of LDS", bytes);
+    int nb2 = (n_tiles + 1) / 2;
+    if (nb2 > NUM_CU) nb2 = NUM_CU;
+    if (head_mode == 1) {
+      static bool attr = false;
+      if (!attr) { if (int rc = raise_lds(gru_step2_kernel<1>, "gru_forward")) return rc; attr = true; }
+      hipLaunchKernelGGL(gru_step2_kernel<1>, dim3(nb2), dim3(4 * WAVE), bytes, as_stream(stream), a);
+    } else {
+      static bool attr = false;
+      if (!attr) { if (int rc = raise_lds(gru_step2_kernel<2>, "gru_forward")) return rc; attr = true; }
+      hipLaunchKernelGGL(gru_step2_kernel<2>, dim3(nb2), dim3(4 * WAVE), bytes, as_stream(stream), a);
+    }
     MAPPO_CHECK_LAUNCH("gru_forward");
     return MAPPO_OK;
   }
