@@ -281,6 +281,18 @@ int mappo_gru_forward(const float *params, const mappo_net_desc *desc /*host*/, 
                       int32_t head_mode, float *out, const float *avail /*[B][A] or NULL*/, int32_t deterministic,
                       uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions, float *logp,
                       mappo_stream_t stream);
+/* One rollout step (L = 1) of a recurrent actor AND critic in one launch (r_actor_critic.py:43-70 + :146-165 on the same Nc rows):
+ * actions / logp [Nc] sampled from the actor's head, values [Nc] from the critic's, next states to *_h_last [Nc][64]. */
+int mappo_gru_step_dual(const float *actor_params, const mappo_net_desc *actor_desc /*host*/, const float *actor_featT /*[64][Nc]*/,
+                        const float *actor_h0 /*[Nc][64]*/, float *actor_h_last, const float *critic_params,
+                        const mappo_net_desc *critic_desc /*host*/, const float *critic_featT, const float *critic_h0,
+                        float *critic_h_last, const float *masks /*[Nc]*/, int32_t Nc, const float *avail /*[Nc][A] or NULL*/,
+                        int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
+                        float *logp, float *values, mappo_stream_t stream);
+/* Trunk features of two networks (same layer_N / activation, in_dim <= 64) on the same B rows in one launch. */
+int mappo_mlp_features_dual(const float *params_a, const mappo_net_desc *desc_a /*host*/, const float *x_a, float *featT_a,
+                            const float *params_c, const mappo_net_desc *desc_c /*host*/, const float *x_c, float *featT_c,
+                            int64_t B, mappo_stream_t stream);
 int32_t mappo_gru_backward_slabs(int32_t Nc);
 int mappo_gru_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *scratch, const float *masks,
                        const int32_t *rows, int32_t L, int32_t Nc, int32_t head, const float *avail, const float *actions,

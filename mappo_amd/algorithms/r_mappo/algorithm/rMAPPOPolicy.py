@@ -193,6 +193,13 @@ class R_MAPPOPolicy:
         avail = buffer.available_actions[step].view(R, -1) if use_available_actions else None
         out = (buffer.actions[step].view(R), buffer.action_log_probs[step].view(R))
         masks = buffer.masks[step].view(R, 1)
+        if getattr(self.actor, "_recurrent", False) and getattr(self.critic, "_recurrent", False):
+            from mappo_amd import recurrent
+            if recurrent.can_step_dual(self.actor, self.critic):
+                rnn_a, rnn_c = recurrent.step_dual(self.actor, self.critic, buffer.obs[step].view(R, -1), buffer.share_obs[step].view(R, -1),
+                                                   buffer.rnn_states[step].view(R, -1), buffer.rnn_states_critic[step].view(R, -1), masks,
+                                                   avail, deterministic, out[0], out[1], buffer.value_preds[step].view(R), step)
+                return buffer.actions[step], rnn_a, rnn_c
         # the two networks are independent: the critic runs on a side stream next to the actor (also inside a
         # captured hipGraph, where the fork/join becomes two parallel branches)
         cur = torch.cuda.current_stream()

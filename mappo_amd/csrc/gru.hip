@@ -658,8 +658,7 @@ __global__ __launch_bounds__(128, 1) void gru_fwd_train2_kernel(GruFwdArgs p, Se
 // over k (each wave its own 32 normalised features), wave 0 adds the partner's partial logits and samples / writes the output.
 #define STEP2_PAIR_FLOATS (HID * TP + 3 * TS * TP + 128)     // tHm (later the partial-logit exchange) | tN x 2 | tZ | LN stats
 template <int HM>
-__global__ __launch_bounds__(256, 1) void gru_step2_kernel(GruFwdArgs p) {
-  extern __shared__ __align__(16) float lds[];
+__device__ __forceinline__ void gru_step2_body(const GruFwdArgs &p, float *lds, const int bid, const int nb) {
   const GruLds &m = p.map;
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   const int pair = wv >> 1, w = wv & 1;
@@ -673,7 +672,7 @@ __global__ __launch_bounds__(256, 1) void gru_step2_kernel(GruFwdArgs p) {
   const int64_t B = p.Nc;                                 // L == 1: column = sequence
   const int n_tiles = (p.Nc + TS - 1) / TS;
   const float *sI = lds + m.wih + 32 * w + l31, *sH = lds + m.whh + 32 * w + l31;
-  for (int t0 = blockIdx.x * 2; t0 < n_tiles; t0 += gridDim.x * 2) {        // both pairs make every trip (workgroup barriers inside)
+  for (int t0 = bid * 2; t0 < n_tiles; t0 += nb * 2) {                      // both pairs make every trip (workgroup barriers inside)
     const int tile = t0 + pair;
     const int c = tile * TS + l31;
     const bool ok = tile < n_tiles && c < p.Nc;
@@ -787,6 +786,18 @@ __global__ __launch_bounds__(256, 1) void gru_step2_kernel(GruFwdArgs p) {
     }
     lds_barrier();                                        // the tiles are rewritten by the next trip
   }
+}
+template <int HM>
+__global__ __launch_bounds__(256, 1) void gru_step2_kernel(GruFwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  gru_step2_body<HM>(p, lds, blockIdx.x, gridDim.x);
+}
+// the rollout step of BOTH networks in one launch: workgroups [0, nA) sample the actor's actions, the rest write the critic's
+// values — one queue, no fork / join between the two networks' kernels (their latency was half of a rollout step)
+__global__ __launch_bounds__(256, 1) void gru_step2_dual_kernel(GruFwdArgs a, GruFwdArgs c, int nA) {
+  extern __shared__ __align__(16) float lds[];
+  if ((int)blockIdx.x < nA) gru_step2_body<2>(a, lds, blockIdx.x, nA);
+  else gru_step2_body<1>(c, lds, blockIdx.x - nA, gridDim.x - nA);
 }
 
 // row-local half of the backward over all L x Nc rows; d h' replaces h' in the forward's scratch (component SCR_HS)
@@ -1230,6 +1241,37 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
 
 static int launch_gru_in(bool gates, const float *params, const mappo_net_desc *desc, const float *inT, int64_t B, float *outT,
                          hipStream_t st, const char *who);
+
+extern "C" int mappo_gru_step_dual(const float *actor_params, const mappo_net_desc *actor_desc, const float *actor_featT,
+                                   const float *actor_h0, float *actor_h_last, const float *critic_params,
+                                   const mappo_net_desc *critic_desc, const float *critic_featT, const float *critic_h0,
+                                   float *critic_h_last, const float *masks, int32_t Nc, const float *avail, int32_t deterministic,
+                                   uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions, float *logp,
+                                   float *values, mappo_stream_t stream) {
+  if (int rc = check_rec(actor_desc, "gru_step_dual")) return rc;
+  if (int rc = check_rec(critic_desc, "gru_step_dual")) return rc;
+  MAPPO_REQUIRE(critic_desc->out_dim == 1, "gru_step_dual: critic out_dim must be 1");
+  MAPPO_REQUIRE(actor_params && actor_featT && actor_h0 && critic_params && critic_featT && critic_h0 && masks && actions && logp &&
+                values && Nc > 0, "gru_step_dual: bad arguments");
+  MAPPO_CLEAR_STICKY();
+  GruFwdArgs a = {}, c = {};
+  a.params = actor_params; a.off = net_offsets(*actor_desc); a.xT = actor_featT; a.h0 = actor_h0; a.masks = masks; a.L = 1; a.Nc = Nc;
+  a.A = actor_desc->out_dim; a.head_mode = 2; a.h_last = actor_h_last; a.avail = avail; a.actions = actions; a.logp = logp;
+  a.deterministic = deterministic; a.seed = seed; a.counter = counter; a.counter_dev = counter_dev;
+  c.params = critic_params; c.off = net_offsets(*critic_desc); c.xT = critic_featT; c.h0 = critic_h0; c.masks = masks; c.L = 1; c.Nc = Nc;
+  c.A = 1; c.head_mode = 1; c.h_last = critic_h_last; c.out = values;
+  a.map = c.map = gru_lds(0, 0, true);
+  const size_t bytes = (size_t)(a.map.total + 2 * STEP2_PAIR_FLOATS) * sizeof(float);
+  MAPPO_REQUIRE(bytes <= LDS_DYN_MAX, "gru_step_dual: needs %zu B of LDS", bytes);
+  const int n_tiles = (Nc + TS - 1) / TS;
+  int nb = (n_tiles + 1) / 2;
+  if (nb > NUM_CU / 2) nb = NUM_CU / 2;
+  static bool attr = false;
+  if (!attr) { if (int rc = raise_lds(gru_step2_dual_kernel, "gru_step_dual")) return rc; attr = true; }
+  hipLaunchKernelGGL(gru_step2_dual_kernel, dim3(2 * nb), dim3(4 * WAVE), bytes, as_stream(stream), a, c, nb);
+  MAPPO_CHECK_LAUNCH("gru_step_dual");
+  return MAPPO_OK;
+}
 
 extern "C" int32_t mappo_gru_backward_slabs(int32_t Nc) {
   const int n_tiles = (Nc + TS - 1) / TS;

@@ -704,6 +704,12 @@ __global__ __launch_bounds__(256, 1) void features16_kernel(FwdArgs a) {
   extern __shared__ __align__(16) float lds[];
   forward16_body<RELU, LN, 2>(a, lds, blockIdx.x, gridDim.x);
 }
+template <bool RELU, int LN>
+__global__ __launch_bounds__(256, 1) void features16_dual_kernel(FwdArgs a, FwdArgs c, int nA) {
+  extern __shared__ __align__(16) float lds[];
+  if ((int)blockIdx.x < nA) forward16_body<RELU, LN, 2>(a, lds, blockIdx.x, nA);
+  else forward16_body<RELU, LN, 2>(c, lds, blockIdx.x - nA, gridDim.x - nA);
+}
 
 // ------------------------------------------------------------------------------------------------
 // diagnostic build only (-DMLP_STAMPS, scripts/stamps.py): per-phase cycle shares of the update kernel.
@@ -1422,6 +1428,54 @@ int launch_features16(const FwdArgs &a_in, hipStream_t st) {
   }
   if (rc) return rc;
   MAPPO_CHECK_LAUNCH("mlp_features");
+  return MAPPO_OK;
+}
+
+template <bool R, int L>
+static int features16_dual_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const FwdArgs &a, const FwdArgs &c, int nA) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)features16_dual_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((features16_dual_kernel<R, L>), grid, block, lds_bytes, st, a, c, nA);
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_mlp_features_dual(const float *params_a, const mappo_net_desc *desc_a, const float *x_a, float *featT_a,
+                                       const float *params_c, const mappo_net_desc *desc_c, const float *x_c, float *featT_c,
+                                       int64_t B, mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(desc_a, "mlp_features_dual")) return rc;
+  if (int rc = check_desc_trunk(desc_c, "mlp_features_dual")) return rc;
+  MAPPO_REQUIRE(desc_a->in_dim <= MAXD && desc_c->in_dim <= MAXD, "mlp_features_dual: in_dim > %d goes through mlp_features", MAXD);
+  MAPPO_REQUIRE(desc_a->layer_N == desc_c->layer_N && desc_a->use_relu == desc_c->use_relu,
+                "mlp_features_dual: the networks must share layer_N and the activation");
+  MAPPO_REQUIRE(params_a && x_a && featT_a && params_c && x_c && featT_c && B > 0, "mlp_features_dual: bad arguments");
+  MAPPO_CLEAR_STICKY();
+  const int64_t n_tiles = (B + 15) / 16;
+  const int want = n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1);
+  int nw = fit_waves(*desc_a, want);
+  const int nwc = fit_waves(*desc_c, want);
+  nw = nw < nwc ? nw : nwc;
+  FwdArgs a = {}, c = {};
+  a.params = params_a; a.x = x_a; a.out = featT_a; a.desc = *desc_a; a.B = B; a.off = net_offsets(a.desc); a.map = lds_map(a.desc, nw);
+  c.params = params_c; c.x = x_c; c.out = featT_c; c.desc = *desc_c; c.B = B; c.off = net_offsets(c.desc); c.map = lds_map(c.desc, nw);
+  const int totA = a.map.total, totC = c.map.total;
+  const size_t lds_bytes = (size_t)(totA > totC ? totA : totC) * sizeof(float);
+  MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "mlp_features_dual: needs %zu B of LDS", lds_bytes);
+  int64_t nb = (n_tiles + nw - 1) / nw;
+  if (nb > NUM_CU) nb = NUM_CU;
+  dim3 grid((unsigned)(2 * nb)), block(WAVE * nw);
+  const bool relu = desc_a->use_relu != 0;
+  int rc;
+  switch (desc_a->layer_N) {
+    case 0: rc = relu ? features16_dual_launch<true, 0>(grid, block, lds_bytes, as_stream(stream), a, c, (int)nb) : features16_dual_launch<false, 0>(grid, block, lds_bytes, as_stream(stream), a, c, (int)nb); break;
+    case 1: rc = relu ? features16_dual_launch<true, 1>(grid, block, lds_bytes, as_stream(stream), a, c, (int)nb) : features16_dual_launch<false, 1>(grid, block, lds_bytes, as_stream(stream), a, c, (int)nb); break;
+    default: rc = relu ? features16_dual_launch<true, 2>(grid, block, lds_bytes, as_stream(stream), a, c, (int)nb) : features16_dual_launch<false, 2>(grid, block, lds_bytes, as_stream(stream), a, c, (int)nb); break;
+  }
+  if (rc) return rc;
+  MAPPO_CHECK_LAUNCH("mlp_features_dual");
   return MAPPO_OK;
 }
 

@@ -64,6 +64,29 @@ def actor_step(actor, obs, rnn_states, masks, avail, deterministic, actions_f, l
     return h_next
 
 
+def can_step_dual(actor, critic):
+    """Both networks recurrent with narrow inputs and the same trunk shape: their rollout step runs as two dual launches."""
+    da, dc = actor.desc, critic.desc
+    return (da.recurrent and dc.recurrent and da.in_dim <= 64 and dc.in_dim <= 64 and da.layer_N == dc.layer_N
+            and da.use_relu == dc.use_relu and actor._recurrent_N == 1 and critic._recurrent_N == 1)
+
+
+def step_dual(actor, critic, obs, cent_obs, rnn_a, rnn_c, masks, avail, deterministic, actions_f, logp, values, counter):
+    """R_Actor.forward + R_Critic.forward of one rollout step on the same rows, as TWO launches on one stream (features of
+    both networks; GRU step + head of both networks) instead of two 2-kernel chains on two queues — the fork / join latency
+    between the queues was as long as the kernels.  Returns the next (actor, critic) states [Nc, 1, H]."""
+    Nc = obs.shape[0]
+    dev = actor.device_
+    sa, sc = _scratch.get(dev, 1, Nc, False, "actor"), _scratch.get(dev, 1, Nc, False, "critic")
+    ops.mlp_features_dual(actor.flat, actor.desc, obs, sa["featT"], critic.flat, critic.desc, cent_obs, sc["featT"], Nc)
+    ha = torch.empty(Nc, 1, H, dtype=torch.float32, device=dev)
+    hc = torch.empty(Nc, 1, H, dtype=torch.float32, device=dev)
+    ops.gru_step_dual(actor.flat, actor.desc, sa["featT"], rnn_a.reshape(Nc, H), ha.view(Nc, H), critic.flat, critic.desc, sc["featT"],
+                      rnn_c.reshape(Nc, H), hc.view(Nc, H), masks.reshape(Nc), Nc, avail, deterministic, actor._seed, counter,
+                      actor._counter_dev, actions_f, logp, values.view(Nc))
+    return ha, hc
+
+
 def actor_sequence_logits(actor, obs, rnn_states, masks):
     """Pre-mask logits for every row of a (L*Nc)-row time-major batch (evaluate_actions, r_actor_critic.py:72-107)."""
     B = obs.shape[0]
