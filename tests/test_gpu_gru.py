@@ -396,3 +396,28 @@ def test_gru_backward_with_dx_matches_deferred_input_backward(M):
     for k in (0, 2):
         for x, y in zip(outs[k], outs[k + 1]):
             np.testing.assert_array_equal(y, x)                             # with / without dxT: identical
+
+
+def test_recurrent_step_dual_matches_separate_kernels(M):
+    """mappo_mlp_features_dual + mappo_gru_step_dual (both networks per launch) == the per-network launches
+    (mappo_mlp_features + mappo_gru_forward head modes 2 / 1), bit for bit: actions, log-probs, values, next states."""
+    from mappo_amd import recurrent
+    a = make_args(M, use_recurrent_policy=True, algorithm_name="rmappo")
+    pol = M.R_MAPPOPolicy(a, [30], [48], M.Discrete(9))
+    assert recurrent.can_step_dual(pol.actor, pol.critic)
+    R, H, A = 3 * 37 + 5, 64, 9
+    g = torch.Generator(device="cuda").manual_seed(4)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    obs, cent, ha, hc = rnd(R, 30), rnd(R, 48), rnd(R, 1, H), rnd(R, 1, H)
+    masks = (torch.rand(R, 1, device="cuda", generator=g) > 0.3).float()
+    avail = (torch.rand(R, A, device="cuda", generator=g) < 0.7).float()
+    avail[:, 0] = 1.0
+    act1, lp1, v1 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, 1, device="cuda")
+    na1 = recurrent.actor_step(pol.actor, obs, ha, masks, avail, False, act1, lp1, counter=7)
+    nc1 = recurrent.critic_forward(pol.critic, cent, hc, masks, v1)
+    act2, lp2, v2 = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    na2, nc2 = recurrent.step_dual(pol.actor, pol.critic, obs, cent, ha, hc, masks, avail, False, act2, lp2, v2, 7)
+    for x, y in ((act1, act2), (lp1, lp2), (v1.view(R), v2), (na1, na2), (nc1, nc2)):
+        np.testing.assert_array_equal(y.cpu().numpy(), x.cpu().numpy())
+    picked = torch.gather(avail, 1, act2.long().view(R, 1))
+    assert float(picked.min()) == 1.0
