@@ -186,7 +186,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dp = os.environ.get("MAPPO_BENCH_FORCE_DP") == "1"     # rehearsal of the data-parallel code path on ONE rank
+    result_out = sys.stdout
     if world > 1 or force_dp:
+        # RCCL prints its version banner on stdout when a communicator is created; the contract is ONE JSON line on stdout, so
+        # the process's fd 1 is pointed at stderr and the JSON line goes to a duplicate of the original stdout
+        sys.stdout.flush()
+        result_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
@@ -306,7 +312,7 @@ def main():
                 out["cpu_baseline"] = dict(value=None, unit="agent-steps/s", cores=n_threads, kind="port", sample=f"failed: {e}")
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if world > 1 or force_dp:
         import torch.distributed as dist
         dist.barrier()
