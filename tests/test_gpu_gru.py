@@ -421,3 +421,28 @@ def test_recurrent_step_dual_matches_separate_kernels(M):
         np.testing.assert_array_equal(y.cpu().numpy(), x.cpu().numpy())
     picked = torch.gather(avail, 1, act2.long().view(R, 1))
     assert float(picked.min()) == 1.0
+
+
+@pytest.mark.parametrize("recurrent", [False, True])
+def test_update_actor_toggle_across_graph_replays(M, recurrent):
+    """R_MAPPO.train(update_actor=...) replayed from hipGraphs keyed by the flag: the host-side switch (Adam skips the actor,
+    r_mappo.py:143-148 with grad None) is applied eagerly before every launch sequence, so a replay never inherits the mode of
+    the previous call: the actor's parameters move exactly in the update_actor=True calls, the critic's in all of them."""
+    T, N, Ma = 10, 8, 3
+    a = make_args(M, episode_length=T, n_rollout_threads=N, ppo_epoch=2, num_mini_batch=1, lr=7e-4, critic_lr=7e-4,
+                  use_recurrent_policy=recurrent, algorithm_name="rmappo" if recurrent else "mappo", data_chunk_length=5)
+    env = M.SyntheticMPEEnv(N, Ma, 18, 5, T, seed=3)
+    runner = M.MPERunner(dict(all_args=a, envs=env, eval_envs=None, num_agents=Ma, device=torch.device("cuda"), run_dir=None))
+    runner.warmup()
+    pol, tr, buf = runner.policy, runner.trainer, runner.buffer
+    lo, mid, hi = pol.seg_bounds
+    runner.rollout()
+    torch.cuda.synchronize()
+    for flag in (True, True, True, False, False, False, True, False, True):
+        before = pol.flat_params.clone()
+        tr.train(buf, update_actor=flag)
+        torch.cuda.synchronize()
+        moved_a = bool((pol.flat_params[lo:mid] != before[lo:mid]).any())
+        moved_c = bool((pol.flat_params[mid:hi] != before[mid:hi]).any())
+        assert moved_a == flag and moved_c, (flag, moved_a, moved_c)
+    assert sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graphs.values()) == 2
