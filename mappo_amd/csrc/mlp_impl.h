@@ -408,11 +408,15 @@ __device__ __forceinline__ void wide_row_stats(const float *__restrict__ xr, int
                                                float &rstd) {
   mean = 0.f; rstd = 1.f;
   if (!feature_norm) return;
+  // unconditional loads (a lane without a row reads row 0: finite values nobody uses) and eight of them in flight per trip:
+  // as a predicated one-load-per-trip loop the two passes cost ~160 memory round trips each
   float s0 = 0.f;
-  if (ok) for (int k = half; k < D; k += 2) s0 += xr[k];
+#pragma unroll 8
+  for (int k = half; k < D; k += 2) s0 += xr[k];
   mean = xhalf_sum(s0) / (float)D;
   float q = 0.f;
-  if (ok) for (int k = half; k < D; k += 2) { const float c = xr[k] - mean; q += c * c; }
+#pragma unroll 8
+  for (int k = half; k < D; k += 2) { const float c = xr[k] - mean; q += c * c; }
   rstd = 1.0f / sqrtf(xhalf_sum(q) / (float)D + LN_EPS);
 }
 
