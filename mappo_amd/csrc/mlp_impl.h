@@ -425,12 +425,12 @@ __device__ __forceinline__ void wide_commit_chunk(float *tX, const float *__rest
                                                   int l31, int half) {
   float v[TS];
 #pragma unroll
+  for (int j = 0; j < TS; ++j) v[j] = xr[min(c0 + 2 * j + half, D - 1)];          // unconditional, clamped: all 32 in flight
+#pragma unroll
   for (int j = 0; j < TS; ++j) {
     const int k = c0 + 2 * j + half;
-    v[j] = (ok && k < D) ? xr[k] : mean;          // (mean - mean) * rstd = 0 for padding
+    tX[(2 * j + half) * TP + l31] = (ok && k < D) ? (v[j] - mean) * rstd : 0.f;   // padding columns / rows contribute 0
   }
-#pragma unroll
-  for (int j = 0; j < TS; ++j) tX[(2 * j + half) * TP + l31] = (v[j] - mean) * rstd;
 }
 
 // acc (2 tiles of 32 features) <- bias
@@ -1867,9 +1867,13 @@ __global__ __launch_bounds__(256, 1) void wide_l1_bwd_kernel(WideArgs p) {
     const int n_valid = (int)min((int64_t)TS, p.B - base);
     const bool ok = l31 < n_valid;
     // dz1 tile [f][s] (feature-major source: 128-B segments)
-    for (int e = lane; e < HID * TS; e += WAVE) {
-      const int f = e >> 5, s = e & 31;
-      tD[f * TP + s] = (s < n_valid) ? dz1T[(int64_t)f * p.B + base + s] : 0.f;
+    {
+      float v[HID / 2];                                // lane (s = l31, half) takes features 2 i + half: all 32 loads in flight
+      const int64_t col = base + min(l31, n_valid - 1);
+#pragma unroll
+      for (int i = 0; i < HID / 2; ++i) v[i] = dz1T[(int64_t)(2 * i + half) * p.B + col];
+#pragma unroll
+      for (int i = 0; i < HID / 2; ++i) tD[(2 * i + half) * TP + l31] = ok ? v[i] : 0.f;
     }
     const int64_t row = ok ? (p.rows ? (int64_t)p.rows[base + l31] : base + l31) : 0;
     const float mean0 = ok ? stats[base + l31] : 0.f, rstd0 = ok ? stats[p.B + base + l31] : 1.f;
