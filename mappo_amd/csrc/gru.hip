@@ -440,11 +440,7 @@ __device__ __forceinline__ void gru_head_backward(f32x16 (&dh)[2], const GruBwdA
     if (lane < TS) {
       float *zl = tZ + lane * TP;
       if (ok) {
-        uint32_t dead = 0u;
-        if (p.avail) {
-          const float *av = p.avail + brow * A;
-          for (int a = 0; a < A; ++a) dead |= (av[a] == 0.f ? 1u : 0u) << a;
-        }
+        const uint32_t dead = p.avail ? avail_dead_mask(p.avail + brow * A, A) : 0u;
         actor_loss_lane(zl, A, dead, (int)p.actions[brow], p.old_logp[brow], p.adv[brow], p.active[brow], p.cfg, ls.scale_pi, lacc);
       } else {
         for (int a = 0; a < A; ++a) zl[a] = 0.f;
@@ -680,6 +676,11 @@ __device__ __forceinline__ void gru_step2_body(const GruFwdArgs &p, float *lds, 
     const int n_valid = tile < n_tiles ? min(TS, p.Nc - tile * TS) : 0;
     const int64_t hrow = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
     const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[cc] : (int64_t)cc] : 0.f;
+    uint32_t dead = 0u;                                   // the sampling lane's availability mask, in flight under the products
+    if (HM == 2 && p.avail) {
+      const int64_t arow = n_valid > 0 ? (int64_t)tile * TS + min(lane, n_valid - 1) : 0;       // a pair without a tile reads row 0
+      dead = avail_dead_mask(p.avail + arow * p.A, p.A);
+    }
     float bx[HID / 2];
 #pragma unroll
     for (int kk = 0; kk < HID / 2; ++kk) bx[kk] = p.xT[(int64_t)(2 * kk + half) * B + cc];
@@ -778,8 +779,7 @@ __device__ __forceinline__ void gru_step2_body(const GruFwdArgs &p, float *lds, 
         const int64_t i = row0 + lane;
         const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
         float action, logp;
-        categorical_act_lane(tZ + lane * TP, p.A, p.avail ? p.avail + i * p.A : nullptr, p.deterministic != 0, p.seed, ctr, (uint64_t)i,
-                             action, logp);
+        categorical_act_mask(tZ + lane * TP, p.A, dead, p.deterministic != 0, p.seed, ctr, (uint64_t)i, action, logp);
         p.actions[i] = action;
         p.logp[i] = logp;
       }

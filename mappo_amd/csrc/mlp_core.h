@@ -254,12 +254,34 @@ __device__ __forceinline__ float critic_loss_lane(float v, float vo, float ret, 
 }
 
 // categorical epilogue of get_actions (distributions.py:14-28,64-68): mask, argmax | inverse-CDF sample, log-prob
+// bit a set <=> available_actions[a] == 0 (A <= 32).  Batches of eight unconditional clamped loads: read one per trip inside
+// the softmax loop, every action cost a memory round trip at the very end of a rollout step.
+__device__ __forceinline__ uint32_t avail_dead_mask(const float *__restrict__ av, int A) {
+  uint32_t dead = 0u;
+  for (int a0 = 0; a0 < A; a0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = av[min(a0 + j, A - 1)];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dead |= ((a0 + j < A && v[j] == 0.f) ? 1u : 0u) << ((a0 + j) & 31);
+  }
+  return dead;
+}
+
+__device__ __forceinline__ void categorical_act_mask(float *zl, int A, uint32_t dead, bool deterministic, uint64_t seed,
+                                                     uint64_t ctr, uint64_t index, float &action, float &logp);
+
 __device__ __forceinline__ void categorical_act_lane(float *zl, int A, const float *av, bool deterministic, uint64_t seed,
+                                                     uint64_t ctr, uint64_t index, float &action, float &logp) {
+  categorical_act_mask(zl, A, av ? avail_dead_mask(av, A) : 0u, deterministic, seed, ctr, index, action, logp);
+}
+
+__device__ __forceinline__ void categorical_act_mask(float *zl, int A, uint32_t dead, bool deterministic, uint64_t seed,
                                                      uint64_t ctr, uint64_t index, float &action, float &logp) {
   float zmax = -FLT_MAX;
   for (int a = 0; a < A; ++a) {
     float za = zl[a];
-    if (av && av[a] == 0.f) { za = -1e10f; zl[a] = za; }
+    if ((dead >> a) & 1u) { za = -1e10f; zl[a] = za; }
     zmax = fmaxf(zmax, za);
   }
   float se = 0.f;
