@@ -139,6 +139,60 @@ class SMACRunner(Runner):
             share_obs = obs
         b.insert_env(share_obs, obs, rewards, masks, rnn_a, rnn_c, bad_masks, active_masks, available_actions)
 
+    # smac_runner.py:160-214
+    @torch.no_grad()
+    def eval(self, total_num_steps):
+        """Deterministic `act` on the eval envs until `eval_episodes` episodes have ended: per-episode reward sums
+        (`eval_average_episode_rewards`) and the win rate from `infos[i][0]['won']`.  rnn states and masks of an env are reset
+        when all of its agents report done, as in the training rollout.  Returns the win rate."""
+        envs = self.eval_envs
+        if envs is None:
+            return None
+        dev = self.device
+        N, Ma = self.n_eval_rollout_threads, self.num_agents
+        R = N * Ma
+        f32 = lambda x: x.to(dev, torch.float32) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x), dtype=torch.float32).to(dev)
+        obs, share_obs, avail = envs.reset()
+        rnn_states = torch.zeros(R, self.recurrent_N, self.hidden_size, device=dev)
+        masks = torch.ones(R, 1, device=dev)
+        battles_won, episodes = 0, 0
+        # per-env running sums (the reference keeps ONE list for all eval threads and clears it whenever any of them ends,
+        # smac_runner.py:186,199-200: with more than one eval thread that mixes episodes and, on current numpy, breaks when two
+        # end in the same step; the per-env sum is what `eval_average_episode_rewards` is meant to average)
+        episode_rewards, running = [], np.zeros((N, Ma, 1), dtype=np.float32)
+        n_eval = int(getattr(self.all_args, "eval_episodes", 32))
+        win_rate = 0.0
+        while True:
+            self.trainer.prep_rollout()
+            actions, rnn_states = self.trainer.policy.act(f32(obs).reshape(R, -1), rnn_states, masks, f32(avail).reshape(R, -1),
+                                                          deterministic=True)
+            actions = actions.view(N, Ma, -1)
+            if getattr(envs, "needs_host_actions", False):
+                actions = _t2n(actions)
+            obs, share_obs, rewards, dones, infos, avail = envs.step(actions)
+            running += _t2n(f32(rewards)).reshape(N, Ma, 1)
+            dones_env = torch.as_tensor(dones).to(dev).view(N, Ma).all(dim=1)                # :190
+            keep = (~dones_env).to(torch.float32).view(N, 1).expand(N, Ma).reshape(R)
+            rnn_states = rnn_states.view(R, self.recurrent_N, -1) * keep.view(R, 1, 1)       # :192
+            masks = keep.view(R, 1).clone()                                                  # :194-195
+            for i in np.nonzero(_t2n(dones_env))[0]:                                          # :197-203
+                episodes += 1
+                episode_rewards.append(running[i].copy())
+                running[i] = 0.0
+                if not torch.is_tensor(infos) and infos is not None and infos[i][0].get("won", False):
+                    battles_won += 1
+            if episodes >= n_eval:                                                           # :205-214
+                self.log_env({"eval_average_episode_rewards": np.array(episode_rewards)}, total_num_steps)
+                win_rate = battles_won / episodes
+                print("eval win rate is {}.".format(win_rate))
+                if self.use_wandb:
+                    import wandb
+                    wandb.log({"eval_win_rate": win_rate}, step=total_num_steps)
+                elif self.writter is not None:
+                    self.writter.add_scalars("eval_win_rate", {"eval_win_rate": win_rate}, total_num_steps)
+                break
+        return win_rate
+
     def log_train(self, train_infos, total_num_steps):
         train_infos["average_step_rewards"] = float(self.buffer.rewards.mean().item())       # :154
         super().log_train(train_infos, total_num_steps)

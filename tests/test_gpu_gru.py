@@ -446,3 +446,46 @@ def test_update_actor_toggle_across_graph_replays(M, recurrent):
         moved_c = bool((pol.flat_params[mid:hi] != before[mid:hi]).any())
         assert moved_a == flag and moved_c, (flag, moved_a, moved_c)
     assert sum(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graphs.values()) == 2
+
+
+def test_smac_runner_eval_loop(M):
+    """SMACRunner.eval (smac_runner.py:160-214): deterministic act with availability masks until `eval_episodes` env
+    terminations; the win rate it reports equals the env's own count, chosen actions are available ones."""
+    from mappo_amd.runner.shared.smac_runner import SMACRunner
+    from mappo_amd.envs.synthetic import SyntheticSMACEnv
+    N, Ma, D, S, A = 5, 3, 30, 48, 9
+
+    class HostInfoEnv(SyntheticSMACEnv):
+        """the synthetic env with SMAC's host-side infos: [[{'won': ...}] * agents] per env"""
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.ended, self.won, self.picked_ok, self._avail = 0, 0, True, None
+
+        def reset(self):
+            out = super().reset()
+            self._avail = out[2]
+            return out
+
+        def step(self, actions):
+            act = torch.as_tensor(actions).to(self.device).long().view(self.N, self.M, 1)
+            self.picked_ok &= bool(torch.gather(self._avail, -1, act).min() == 1.0)
+            obs, share, rew, dones, bad, avail = super().step(actions)
+            self._avail = avail
+            done_env = dones.all(dim=1).cpu().numpy()
+            infos = []
+            for i in range(self.N):
+                won = bool(done_env[i]) and (self.ended + i) % 2 == 0
+                infos.append([{"won": won, "bad_transition": False} for _ in range(self.M)])
+                if done_env[i]:
+                    self.won += int(won)
+            self.ended += int(done_env.sum())
+            return obs, share, rew, dones, infos, avail
+
+    a = make_args(M, episode_length=8, n_rollout_threads=N, n_eval_rollout_threads=N, use_recurrent_policy=True, algorithm_name="rmappo",
+                  env_name="StarCraft2", use_eval=True, eval_episodes=7)
+    env = SyntheticSMACEnv(N, Ma, D, S, A, seed=2)
+    eval_env = HostInfoEnv(N, Ma, D, S, A, p_death=0.05, p_term=0.15, seed=3)
+    runner = SMACRunner(dict(all_args=a, envs=env, eval_envs=eval_env, num_agents=Ma, device=torch.device("cuda"), run_dir=None))
+    rate = runner.eval(0)
+    assert eval_env.ended >= 7 and eval_env.picked_ok
+    assert rate == eval_env.won / eval_env.ended
