@@ -231,10 +231,12 @@ int mappo_critic_update(const float *params, const mappo_net_desc *desc /*host*/
                         const double *mb_moments /*[4]*/, const mappo_ppo_cfg *cfg /*host*/, float *slabs,
                         int64_t slab_stride, int64_t slab_col0, double *partials, float *wide_ws /*or NULL*/,
                         int32_t n_blocks, mappo_stream_t stream);
-/* mappo_actor_update + mappo_critic_update in ONE launch (in_dim <= 64, shared layer_N / activation): each network runs
- * on half the CUs and writes mappo_dual_update_slabs(B) slab rows of its own columns and as many partial rows.  Alone,
- * each kernel leaves the chip with a ragged last round of tiles; side by side they share one. */
-int32_t mappo_dual_update_slabs(int64_t B);
+/* mappo_actor_update + mappo_critic_update in ONE launch (in_dim <= 64, shared layer_N / activation).  The networks run side
+ * by side on disjoint CUs (shares proportional to their per-tile cost); each writes its own slab columns and loss partials.
+ * mappo_dual_update_slabs = the slab rows / partial rows the caller provides PER NETWORK: every one of them is written by
+ * the launch (a network with fewer workgroups has its remaining rows zero-filled), so the reduction runs over that count.
+ * layer_N <= 1 and out_dim <= 16 take the one-wave-per-16-sample-tile kernel (csrc/mlp_upd16.h), the rest the pair kernel. */
+int32_t mappo_dual_update_slabs(const mappo_net_desc *actor_desc /*host*/, const mappo_net_desc *critic_desc /*host*/, int64_t B);
 int mappo_actor_critic_update(const float *actor_params, const mappo_net_desc *actor_desc /*host*/, const float *obs,
                               const float *critic_params, const mappo_net_desc *critic_desc /*host*/, const float *share_obs,
                               const int32_t *rows, int64_t B, const float *avail, const float *actions, const float *old_logp,

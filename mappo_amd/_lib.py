@@ -63,7 +63,7 @@ SIGNATURES = {
                                      _I64, _P, _P, _I32, _P]),
     "mappo_critic_update": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _P, _P, _P, C.POINTER(PpoCfg), _P, _I64,
                                       _I64, _P, _P, _I32, _P]),
-    "mappo_dual_update_slabs": (_I32, [_I64]),
+    "mappo_dual_update_slabs": (_I32, [C.POINTER(NetDesc), C.POINTER(NetDesc), _I64]),
     "mappo_actor_critic_update": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                             C.POINTER(PpoCfg), _P, _I64, _I64, _I64, _P, _P, _P]),
     "mappo_update_stats": (C.c_int, [_P, _I32, _P, _I32, _P, C.POINTER(PpoCfg), _P, _P, _P]),

@@ -182,7 +182,7 @@ class R_MAPPO():
                 ops.actor_critic_update(pol.actor.flat, pol.actor.desc, src["obs"], pol.critic.flat, pol.critic.desc, src["share_obs"],
                                         rows, B, src["avail"], src["actions"], src["old_logp"], src["adv"], src["active"], src["v_old"],
                                         src["returns"], vn_state, self._mb_moments, cfg, slabs, P, 0, pol.seg_bounds[1], pa, pc)
-                n_pa = n_pc = ops.dual_update_slabs(B)
+                n_pa = n_pc = ops.dual_update_slabs(pol.actor.desc, pol.critic.desc, B)
                 self._slab_rows = n_pa
             else:
                 if update_actor:
@@ -347,7 +347,7 @@ class R_MAPPO():
         if self._epochs is not None:
             # (rows of loss partials the update kernels wrote; not taken from a side effect of _update_kernels: under data
             # parallelism the epochs may have been graph replays, during which no Python runs)
-            n_rows = ops.dual_update_slabs(S) if (update_actor and self._dual_update and self.policy.can_fuse_step()) \
+            n_rows = ops.dual_update_slabs(self.policy.actor.desc, self.policy.critic.desc, S) if (update_actor and self._dual_update and self.policy.can_fuse_step()) \
                 else ops.mlp_backward_slabs(S)
             ops.update_stats(self._pa if update_actor else None, n_rows, self._pc, n_rows, self._mb_moments, self._cfg, self._stats,
                              self._acc)

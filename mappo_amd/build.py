@@ -19,7 +19,20 @@ def _stale(target, deps):
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(not os.path.exists(d) or os.path.getmtime(d) > t for d in deps)
+
+
+def _depfile_deps(depfile):
+    """Prerequisites recorded by `hipcc -MD -MF` for one object (None if there is no usable depfile yet)."""
+    try:
+        with open(depfile) as f:
+            text = f.read().replace("\\\n", " ")
+    except OSError:
+        return None
+    if ":" not in text:
+        return None
+    deps = [d for d in text.split(":", 1)[1].split() if not d.startswith("/opt/rocm")]
+    return deps or None
 
 
 def build(force=False, verbose=True, extra_flags=(), lib=None, objdir=None):
@@ -34,8 +47,11 @@ def build(force=False, verbose=True, extra_flags=(), lib=None, objdir=None):
     for s in srcs:
         o = s[:-4] + ".o" if objdir is None else os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + headers):
-            cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-c", s, "-o", o]
+        # the object's own header list (from the last compile) decides staleness: editing one kernel header does not
+        # rebuild the translation units that never include it
+        deps = _depfile_deps(o + ".d")
+        if force or _stale(o, deps if deps is not None else [s] + headers):
+            cmd = [HIPCC] + FLAGS + list(extra_flags) + ["-MD", "-MF", o + ".d", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -35,6 +35,7 @@
 // workgroup and sweeps the row tiles (dz1 goes through a feature-major HBM scratch).
 // Limits of this build: hidden == 64, out_dim <= 32, layer_N <= 2, in_dim <= 512.
 #include "mlp_core.h"
+#include <stdlib.h>
 
 #ifdef MLP_TU_MAIN
 extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
@@ -1281,11 +1282,13 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
 }
 
 #include "mlp_upd2.h"
+#include "mlp_upd16.h"
 
 #define LDS_LIMIT (160 * 1024)
 #define LDS_STATIC 1024                      // static __shared__ of the kernels (reduction scratch), rounded up
 #define LDS_DYN_MAX (LDS_LIMIT - LDS_STATIC) // what hipFuncAttributeMaxDynamicSharedMemorySize may be raised to
 #define NUM_CU 256
+#define UPD16_LDS_MAX (LDS_LIMIT - 256)          // the 16-sample-tile update kernels have no static __shared__
 
 // One launch of mlp_update_kernel<RELU, LN, HEAD, *>.  The 72 instantiations of that kernel are spread over the
 // translation units mlp_upd_r{0,1}_l{0,1,2}.hip (one (RELU, LN) pair each, compiled in parallel); mlp.hip holds the
@@ -1298,6 +1301,11 @@ int upd2_inst(bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st
 // actor + critic in one launch (mlp_update2_dual_kernel): translation units mlp_upd2d_r{0,1}_l{0,1,2}.hip
 template <bool R, int L>
 int upd2d_inst(bool wide_a, bool wide_c, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const DualArgs &d);
+// one wave per 16-sample tile (mlp_upd16.h), in_dim <= 64, layer_N <= 1: translation units mlp_upd16_r{0,1}_l{0,1}.hip
+template <bool R, int L>
+int upd16_inst(int head, bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a);
+template <bool R, int L>
+int upd16d_inst(bool wide_a, bool wide_c, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Dual16Args &d);
 
 #ifdef MLP_TU_UPD
 template <bool R, int L, int HEAD, int W>
@@ -1365,6 +1373,46 @@ int upd2d_inst(bool wa, bool wc, dim3 grid, dim3 block, size_t lds_bytes, hipStr
   return wc ? upd2d_launch<R, L, false, true>(grid, block, lds_bytes, st, d) : upd2d_launch<R, L, false, false>(grid, block, lds_bytes, st, d);
 }
 template int upd2d_inst<MLP_UPD_RELU, MLP_UPD_LN>(bool, bool, dim3, dim3, size_t, hipStream_t, const DualArgs &);
+#endif
+
+#ifdef MLP_TU_UPD16
+template <bool R, int L, int HEAD, bool W>
+static int upd16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)UPD16_LDS_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("update16: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update16_kernel<R, L, HEAD, W>), grid, block, lds_bytes, st, a);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+int upd16_inst(int head, bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
+  if (head == 1) return wide ? upd16_launch<R, L, 1, true>(grid, block, lds_bytes, st, a) : upd16_launch<R, L, 1, false>(grid, block, lds_bytes, st, a);
+  return wide ? upd16_launch<R, L, 2, true>(grid, block, lds_bytes, st, a) : upd16_launch<R, L, 2, false>(grid, block, lds_bytes, st, a);
+}
+template int upd16_inst<MLP_UPD_RELU, MLP_UPD_LN>(int, bool, dim3, dim3, size_t, hipStream_t, const Upd16Args &);
+
+template <bool R, int L, bool WA, bool WC>
+static int upd16d_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Dual16Args &d) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16_dual_kernel<R, L, WA, WC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)UPD16_LDS_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("actor_critic_update: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update16_dual_kernel<R, L, WA, WC>), grid, block, lds_bytes, st, d);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+int upd16d_inst(bool wa, bool wc, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Dual16Args &d) {
+  if (wa) return wc ? upd16d_launch<R, L, true, true>(grid, block, lds_bytes, st, d) : upd16d_launch<R, L, true, false>(grid, block, lds_bytes, st, d);
+  return wc ? upd16d_launch<R, L, false, true>(grid, block, lds_bytes, st, d) : upd16d_launch<R, L, false, false>(grid, block, lds_bytes, st, d);
+}
+template int upd16d_inst<MLP_UPD_RELU, MLP_UPD_LN>(bool, bool, dim3, dim3, size_t, hipStream_t, const Dual16Args &);
 #endif
 
 #if defined(MLP_TU_MAIN) || defined(MLP_TU_STEP)
@@ -1629,6 +1677,52 @@ extern "C" int mappo_actor_act(const float *params, const mappo_net_desc *desc, 
   return launch_forward<1>(a, as_stream(stream), "actor_act");
 }
 
+// ---- one wave per 16-sample tile (mlp_upd16.h) ---------------------------------------------------------------------
+#define UPD16_WAVES (UPD16_THREADS / WAVE)
+static bool upd16_eligible(const mappo_net_desc &d, bool actor) {
+  const char *e = getenv("MAPPO_UPD16");               // diagnostic switch: MAPPO_UPD16=0 keeps the pair kernel (A/B timing, cross-checks)
+  if (e && e[0] == '0') return false;
+  return d.in_dim <= MAXD && d.layer_N <= 1 && !d.recurrent && (actor ? d.out_dim <= 16 : d.out_dim == 1);
+}
+// MFMA instructions per 16-sample tile (+ a flat allowance for the VALU phases): the share of the chip a network gets
+static int upd16_tile_cost(const mappo_net_desc &d, bool actor) {
+  const int C = (d.in_dim + 3) >> 2, nbk = d.in_dim > 32 ? 4 : 2;
+  int c = 4 * C + 16 * nbk + 40;
+  if (d.layer_N > 0) c += 3 * 64;
+  if (actor) c += 16 + 16 + 4 * ((d.out_dim + 3) >> 2);
+  return c;
+}
+static size_t upd16_lds_floats(const mappo_net_desc &d, bool actor) {
+  const bool w = d.in_dim > 32;
+  if (actor) {
+    if (d.layer_N > 0) return w ? L16<1, 1, true>::TOTAL : L16<1, 1, false>::TOTAL;
+    return w ? L16<0, 1, true>::TOTAL : L16<0, 1, false>::TOTAL;
+  }
+  if (d.layer_N > 0) return w ? L16<1, 2, true>::TOTAL : L16<1, 2, false>::TOTAL;
+  return w ? L16<0, 2, true>::TOTAL : L16<0, 2, false>::TOTAL;
+}
+static int prep16(Upd16Args &a, bool actor, const char *who) {
+  UpdArgs &u = a.u;
+  u.off = net_offsets(u.desc);
+  MAPPO_REQUIRE(u.slab_col0 >= 0 && u.slab_col0 + u.off.total <= u.slab_stride, "%s: slab column range", who);
+  MAPPO_REQUIRE(upd16_lds_floats(u.desc, actor) * sizeof(float) <= UPD16_LDS_MAX, "%s: needs %zu B of LDS", who,
+                upd16_lds_floats(u.desc, actor) * sizeof(float));
+  a.zero_row0 = a.zero_row1 = 0; a.zero_col0 = 0; a.zero_cols = 0; a.zero_partials = nullptr;
+  return MAPPO_OK;
+}
+// workgroups of the dual launch: the chip's 256 CUs split by the networks' tile costs (few tiles: one tile per wave)
+static void upd16_split(const mappo_net_desc &da, const mappo_net_desc &dc, int64_t B, int &nA, int &nC) {
+  const int64_t n_tiles = (B + 15) / 16;
+  const int64_t want = (n_tiles + UPD16_WAVES - 1) / UPD16_WAVES;
+  const int ca = upd16_tile_cost(da, true), cc = upd16_tile_cost(dc, false);
+  int a = (int)((int64_t)NUM_CU * ca / (ca + cc));
+  if (const char *e = getenv("MAPPO_UPD16_NA")) a = atoi(e);   // diagnostic override of the actor's share (scripts/time_dual.py)
+  a = a < 64 ? 64 : (a > NUM_CU - 64 ? NUM_CU - 64 : a);
+  int c = NUM_CU - a;
+  nA = (int)(want < a ? want : a);
+  nC = (int)(want < c ? want : c);
+}
+
 extern "C" int32_t mappo_mlp_backward_slabs(int64_t B) {
   // number of slabs an update/backward launch writes: one per workgroup, at most one workgroup per CU
   int64_t n_tiles = (B + TS - 1) / TS;
@@ -1653,7 +1747,17 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
   a.stamps = g_stamp_host;
 #endif
   int rc;
-  if (d.in_dim <= MAXD) {
+  if ((HEAD == 1 || HEAD == 2) && upd16_eligible(d, HEAD == 1)) {
+    // one wave per 16-sample tile (mlp_upd16.h)
+    Upd16Args a16 = {};
+    a16.u = a;
+    if (int rc16 = prep16(a16, HEAD == 1, who)) return rc16;
+    const size_t lds_bytes = upd16_lds_floats(d, HEAD == 1) * sizeof(float);
+    dim3 grid((unsigned)nb), block(WAVE * UPD16_WAVES);
+    const bool wide = d.in_dim > 32;
+    if (LN == 0) rc = relu ? upd16_inst<true, 0>(HEAD, wide, grid, block, lds_bytes, st, a16) : upd16_inst<false, 0>(HEAD, wide, grid, block, lds_bytes, st, a16);
+    else rc = relu ? upd16_inst<true, 1>(HEAD, wide, grid, block, lds_bytes, st, a16) : upd16_inst<false, 1>(HEAD, wide, grid, block, lds_bytes, st, a16);
+  } else if (d.in_dim <= MAXD) {
     // pair kernel (mlp_upd2.h): n_pairs tiles in flight per workgroup, two waves each
     const int np = fit_waves(d, 4);
     a.map = lds_map(d, np);
@@ -1759,9 +1863,14 @@ static int prep_pair(UpdArgs &a, int np, const char *who) {
   return MAPPO_OK;
 }
 
-extern "C" int32_t mappo_dual_update_slabs(int64_t B) {
-  // slab rows (= workgroups) EACH network writes in mappo_actor_critic_update: half the CUs each
-  int64_t n_tiles = (B + TS - 1) / TS;
+extern "C" int32_t mappo_dual_update_slabs(const mappo_net_desc *actor_desc, const mappo_net_desc *critic_desc, int64_t B) {
+  // slab rows (= loss-partial rows) the caller provides PER NETWORK for mappo_actor_critic_update; every one of them is written
+  if (actor_desc && critic_desc && upd16_eligible(*actor_desc, true) && upd16_eligible(*critic_desc, false)) {
+    int nA, nC;
+    upd16_split(*actor_desc, *critic_desc, B, nA, nC);
+    return nA > nC ? nA : nC;
+  }
+  int64_t n_tiles = (B + TS - 1) / TS;              // pair kernel: half the CUs each
   return (int32_t)(n_tiles < NUM_CU / 2 ? n_tiles : NUM_CU / 2);
 }
 
@@ -1783,6 +1892,32 @@ extern "C" int mappo_actor_critic_update(const float *actor_params, const mappo_
                     cfg && slabs && actor_partials && critic_partials && B > 0, "actor_critic_update: bad arguments");
   MAPPO_REQUIRE(!cfg->use_valuenorm || vn_state, "actor_critic_update: use_valuenorm needs vn_state");
   MAPPO_CLEAR_STICKY();
+  if (upd16_eligible(*actor_desc, true) && upd16_eligible(*critic_desc, false)) {
+    Dual16Args d = {};
+    UpdArgs &a = d.a.u, &c = d.c.u;
+    a.params = actor_params; a.x = obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = actor_col0;
+    a.desc = *actor_desc; a.B = B; a.avail = avail; a.actions = actions; a.old_logp = old_logp; a.adv = adv; a.active = active;
+    a.mb_moments = mb_moments; a.partials = actor_partials; a.cfg = *cfg;
+    c.params = critic_params; c.x = share_obs; c.rows = rows; c.slabs = slabs; c.slab_stride = slab_stride; c.slab_col0 = critic_col0;
+    c.desc = *critic_desc; c.B = B; c.v_old = v_old; c.returns = returns; c.active = active; c.vn_state = vn_state;
+    c.mb_moments = mb_moments; c.partials = critic_partials; c.cfg = *cfg;
+    if (int rc = prep16(d.a, true, "actor_critic_update")) return rc;
+    if (int rc = prep16(d.c, false, "actor_critic_update")) return rc;
+    upd16_split(a.desc, c.desc, B, d.nA, d.nC);
+    // the network with fewer workgroups: its missing slab / partial rows are zero-filled by the other one's workgroups
+    if (d.nA < d.nC) { d.c.zero_row0 = d.nA; d.c.zero_row1 = d.nC; d.c.zero_col0 = actor_col0; d.c.zero_cols = a.off.total; d.c.zero_partials = actor_partials; }
+    if (d.nC < d.nA) { d.a.zero_row0 = d.nC; d.a.zero_row1 = d.nA; d.a.zero_col0 = critic_col0; d.a.zero_cols = c.off.total; d.a.zero_partials = critic_partials; }
+    const size_t la = upd16_lds_floats(a.desc, true), lc = upd16_lds_floats(c.desc, false);
+    const size_t lds_bytes = (la > lc ? la : lc) * sizeof(float);
+    dim3 grid((unsigned)(d.nA + d.nC)), block(WAVE * UPD16_WAVES);
+    const bool wa = a.desc.in_dim > 32, wc = c.desc.in_dim > 32, relu = a.desc.use_relu != 0;
+    int rc;
+    if (a.desc.layer_N == 0) rc = relu ? upd16d_inst<true, 0>(wa, wc, grid, block, lds_bytes, as_stream(stream), d) : upd16d_inst<false, 0>(wa, wc, grid, block, lds_bytes, as_stream(stream), d);
+    else rc = relu ? upd16d_inst<true, 1>(wa, wc, grid, block, lds_bytes, as_stream(stream), d) : upd16d_inst<false, 1>(wa, wc, grid, block, lds_bytes, as_stream(stream), d);
+    if (rc) return rc;
+    MAPPO_CHECK_LAUNCH("actor_critic_update");
+    return MAPPO_OK;
+  }
   DualArgs d = {};
   UpdArgs &a = d.a, &c = d.c;
   a.params = actor_params; a.x = obs; a.rows = rows; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = actor_col0;
@@ -1799,7 +1934,7 @@ extern "C" int mappo_actor_critic_update(const float *actor_params, const mappo_
   const int ta = a.map.total, tc = c.map.total;
   const size_t lds_bytes = (size_t)(ta > tc ? ta : tc) * sizeof(float);
   MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "actor_critic_update: needs %zu B of LDS", lds_bytes);
-  d.nA = d.nC = mappo_dual_update_slabs(B);
+  d.nA = d.nC = mappo_dual_update_slabs(nullptr, nullptr, B);
 #ifdef MLP_STAMPS
   a.stamps = c.stamps = nullptr;
 #endif

@@ -1,0 +1,5 @@
+// mlp_update16_kernel / mlp_update16_dual_kernel<RELU=false, LN=1> — one wave per 16-sample tile (mlp_upd16.h)
+#define MLP_TU_UPD16
+#define MLP_UPD_RELU false
+#define MLP_UPD_LN 1
+#include "mlp_impl.h"

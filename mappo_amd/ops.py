@@ -299,15 +299,15 @@ def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_s
     _wide(desc, share_obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
 
 
-def dual_update_slabs(B):
-    return int(_lib.load().mappo_dual_update_slabs(int(B)))
+def dual_update_slabs(actor_desc, critic_desc, B):
+    return int(_lib.load().mappo_dual_update_slabs(C.byref(actor_desc), C.byref(critic_desc), int(B)))
 
 
 def actor_critic_update(actor_params, actor_desc, obs, critic_params, critic_desc, share_obs, rows, B, avail, actions, old_logp, adv,
                         active, v_old, returns, vn_state, mb_moments, cfg, slabs, slab_stride, actor_col0, critic_col0,
                         actor_partials, critic_partials):
     """mappo_actor_update + mappo_critic_update in one launch (both in_dim <= 64): each network on half the CUs, writing
-    dual_update_slabs(B) slab rows / partial rows."""
+    dual_update_slabs(actor_desc, critic_desc, B) slab rows / partial rows."""
     rc = _lib.load().mappo_actor_critic_update(_ptr(actor_params), C.byref(actor_desc), _ptr(obs), _ptr(critic_params), C.byref(critic_desc),
                                                _ptr(share_obs), _ptr(rows, torch.int32, allow_none=True), int(B),
                                                _ptr(avail, allow_none=True), _ptr(actions), _ptr(old_logp), _ptr(adv), _ptr(active),

@@ -486,7 +486,7 @@ def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, wit
     ops.slab_reduce(slabs, ns, P, P, grad_f)
     # (1b) both networks in ONE launch (mappo_actor_critic_update), in_dim <= 64
     if D <= 64 and S <= 64:
-        nd = ops.dual_update_slabs(B)
+        nd = ops.dual_update_slabs(da, dc, B)
         slabs_d = torch.zeros(nd, P, device="cuda")
         pda, pdc = ops.update_partials("cuda"), ops.update_partials("cuda")
         ops.actor_critic_update(pa, da, g["obs"], pc, dc, g["sobs"], d_rows, B, g["avail"], g["actions"], g["old"], g["adv"], g["active"],
@@ -495,7 +495,7 @@ def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, wit
         ops.update_stats(pda, nd, pdc, nd, mom, cfg, stats_d)
         grad_d = torch.zeros(P, device="cuda")
         ops.slab_reduce(slabs_d, nd, P, P, grad_d)
-        close(stats_d, stats_f, 1e-9, 1e-12, "stats dual vs separate launches")
+        close(stats_d, stats_f, 1e-6, 1e-9, "stats dual vs separate launches")    # lanes accumulate a handful of samples in fp32, the rest in double
         close_rel_max(grad_d, grad_f.cpu().numpy(), 2e-6, "grad dual vs separate launches")
     # (2) unfused
     logits, values = torch.zeros(B, A, device="cuda"), torch.zeros(B, device="cuda")
