@@ -4,15 +4,18 @@
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one training iteration of BASELINE.json configs[1]: episode_length=25 rollout steps over
-n_rollout_threads=1024 (PER GPU: weak scaling, rollout threads shard across ranks) x 3 agents of MPE
+n_rollout_threads=1024 (--scaling strong, the default: 1024 threads IN TOTAL, sharded over the ranks as north_star and
+BASELINE configs[3]/[4] state it; --scaling weak: 1024 threads PER GPU) x 3 agents of MPE
 simple_spread-shaped synthetic observations (obs 18, share_obs 54, Discrete(5)) with the fused actor/critic
 kernels writing into the HBM replay buffer, the bootstrap value + GAE scan, ppo_epoch=10 x num_mini_batch=1
 PPO updates (forward, fused loss, backward, [RCCL all-reduce], clip + Adam) and after_update.
 
 Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     : the dominant kernel of the step — mlp_update_kernel (critic): forward + value loss + backward of the
-                 critic MLP in one launch, bound by the fp32 MFMA rate; algorithmic flops 6*MACs/sample (forward, dW, dX —
-                 the in-kernel forward recompute is NOT counted) / launch duration from HIP events attached to the dispatch.
+  roofline     : the dominant kernel of the step — mlp_update16_dual_kernel: forward + PPO / value loss + backward of the
+                 actor AND critic MLPs in one launch, bound by the fp32 MFMA rate; algorithmic flops 6*MACs/sample
+                 (forward, dW, dX) / launch duration from HIP events attached to the dispatch.  `traffic` = HBM bytes per
+                 launch from the committed rocprofv3 PMC passes over this very kernel (profiles/r02/dual_update_hbm_pmc.json).
+  gae_roofline : the GAE scan kernel at BASELINE configs[4] per-GPU size (T=400, R=16 384: 105 MB), HBM-bound.
   ppo_loss_roofline : the standalone fused PPO loss kernel (mappo_ppo_loss_fwd_bwd, north_star's HBM-roofline kernel)
                  on this step's buffer and at BASELINE configs[4] size: 4*(3A+8) B/sample / launch duration.
   cpu_baseline : the CPU oracle (a port of the reference's NumPy/torch-CPU path, oracle/mappo_oracle.py) timed on this
@@ -31,9 +34,22 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-HBM_TRAFFIC_CRITIC_UPDATE_BYTES = 2 * 9008 * 1024 + 8124 * 1024     # measured offline (rocprofv3 PMC), profiles/r01/g_update_kernels_hbm_pmc.csv
-HBM_TRAFFIC_DUAL_UPDATE_BYTES = HBM_TRAFFIC_CRITIC_UPDATE_BYTES + 2 * 4498 * 1024 + 6008 * 1024
-MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32 matrix peak
+HBM_PMC_FILE = os.path.join(ROOT, "profiles", "r02", "dual_update_hbm_pmc.json")   # scripts/pmc_hbm.sh: FETCH_SIZE / WRITE_SIZE passes
+
+
+def measured_traffic(kernel, samples):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (separate rocprofv3 --pmc passes, as the microarch
+    guide prescribes: FETCH_SIZE doubled for 16-B-per-lane streaming reads on gfx950, WRITE_SIZE as reported), or None
+    when there is no measurement of this kernel at this size."""
+    try:
+        with open(HBM_PMC_FILE) as f:
+            m = json.load(f)
+    except (OSError, ValueError):
+        return None, "no PMC summary committed"
+    if m.get("kernel") != kernel or int(m.get("samples", -1)) != int(samples):
+        return None, f"PMC summary is for {m.get('kernel')} at {m.get('samples')} samples"
+    return int(m["traffic_bytes"]), m.get("note", "")
 
 
 def ppo_loss_roofline(runner, timer, A):
@@ -77,12 +93,39 @@ def ppo_loss_roofline(runner, timer, A):
     return out
 
 
+def gae_roofline(runner, timer):
+    """The GAE scan kernel at BASELINE configs[4] per-GPU size (T=400, R=256 x 64 = 16 384 series): 16 B per agent-step
+    (read r, v, mask; write ret) + 8 R for the slot-T edge = 105 MB per launch, HIP events on the dispatch."""
+    from mappo_amd import ops
+    dev = runner.buffer.device
+    T, R = 400, 256 * 64
+    g = lambda *s: torch.randn(*s, device=dev)
+    rew, val, ret = g(T, R), g(T + 1, R), torch.empty(T + 1, R, device=dev)
+    masks = (torch.rand(T + 1, R, device=dev) > 0.02).float()
+    vn = runner.trainer.value_normalizer.state if runner.trainer.value_normalizer is not None else None
+    timer.reset(); timer.active = {"gae_scan"}
+    if len(timer.pool) < 12:
+        timer.reserve(12)
+    for _ in range(10):
+        ops.gae_scan(rew, val, val[T].clone(), masks, None, ret, vn, 0.99, 0.95)
+    torch.cuda.synchronize()
+    us = timer.mean_us("gae_scan")
+    timer.active = set()
+    nbytes = 16 * T * R + 8 * R
+    ach = nbytes / (us * 1e-6) / 1e9
+    return dict(bound="hbm", kernel="gae_scan_kernel", agent_steps=T * R, bytes_per_launch=nbytes, launch_us=us, achieved=ach,
+                peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n_rollout_threads", type=int, default=1024, help="per GPU")
+    ap.add_argument("--n_rollout_threads", type=int, default=1024, help="global under --scaling strong, per GPU under weak")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default): n_rollout_threads is the GLOBAL count, sharded over the ranks (north_star's >= 6x at "
+                         "8 GPUs is a strong-scaling target); weak: n_rollout_threads per GPU")
     ap.add_argument("--episode_length", type=int, default=25)
     ap.add_argument("--ppo_epoch", type=int, default=10)
     ap.add_argument("--num_mini_batch", type=int, default=1)
@@ -100,7 +143,7 @@ def make_args(ns):
     a.use_naive_recurrent_policy = False
     a.env_name = "MPE"
     a.episode_length = ns.episode_length
-    a.n_rollout_threads = ns.n_rollout_threads
+    a.n_rollout_threads = ns.local_threads
     a.ppo_epoch = ns.ppo_epoch
     a.num_mini_batch = ns.num_mini_batch
     a.lr = a.critic_lr = 7e-4                         # train_mpe_spread.sh:15-17
@@ -155,35 +198,62 @@ def install_timer(timer):
         setattr(ops, name, wrapped)
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(ns, n_threads):
-    """Oracle iteration on the host cores: same shapes / hyper-parameters / synthetic generator, bounded sample."""
+    """Oracle iterations on the host cores: BASELINE configs[0] shape (N=8, the reference's own CPU case) and
+    this run's configs[1] shape (N=1024 global), each with torch.set_num_threads(1) (the reference default, config.py:168-169)
+    and with all cores; same shapes / hyper-parameters / synthetic generator as the GPU run; bounded: a few iterations."""
     from oracle import mappo_oracle as O
-    torch.set_num_threads(n_threads)
     T, M, D, A = ns.episode_length, 3, 18, 5
-    oa = O.default_args(episode_length=T, n_rollout_threads=ns.n_rollout_threads, ppo_epoch=ns.ppo_epoch,
-                        num_mini_batch=ns.num_mini_batch, lr=7e-4, critic_lr=7e-4)
-    env = O.SyntheticMPEEnvRef(ns.n_rollout_threads, M, D, T, seed=1)
-    runner = O.RunnerRef(oa, env, M, D, D * M, A, seed=1)
-    runner.warmup()
-    # untimed warm-up on 2 of the 10 epochs' worth of work would still cost seconds; warm torch on a tiny twin instead
-    wa = O.default_args(episode_length=T, n_rollout_threads=8, ppo_epoch=2, lr=7e-4, critic_lr=7e-4)
-    w = O.RunnerRef(wa, O.SyntheticMPEEnvRef(8, M, D, T, seed=2), M, D, D * M, A, seed=2)
-    w.warmup(); w.run_iteration()
-    t0 = time.perf_counter()
-    _, timing = runner.run_iteration()
-    dt = time.perf_counter() - t0
-    steps = T * ns.n_rollout_threads * M
-    return dict(value=steps / dt, unit="agent-steps/s", cores=n_threads, kind="port",
-                sample=f"1 iteration (T={T} x N={ns.n_rollout_threads} x M={M} = {steps} agent-steps, ppo_epoch={ns.ppo_epoch}) "
-                       f"of the same workload, torch-CPU/NumPy oracle, {n_threads} threads; "
-                       f"collect {timing['collect']:.2f}s gae {timing['gae']:.3f}s train {timing['train']:.2f}s",
-                seconds=dt)
+
+    def one(N, threads, iters):
+        torch.set_num_threads(threads)
+        oa = O.default_args(episode_length=T, n_rollout_threads=N, ppo_epoch=ns.ppo_epoch, num_mini_batch=ns.num_mini_batch,
+                            lr=7e-4, critic_lr=7e-4)
+        r = O.RunnerRef(oa, O.SyntheticMPEEnvRef(N, M, D, T, seed=1), M, D, D * M, A, seed=1)
+        r.warmup()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            _, timing = r.run_iteration()
+        dt = (time.perf_counter() - t0) / iters
+        return dict(agent_steps_per_s=T * N * M / dt, seconds_per_iteration=dt, threads=threads, n_rollout_threads=N,
+                    split_s={k: round(float(v), 4) for k, v in timing.items()})
+
+    # warm torch's CPU kernels on a tiny twin first
+    one(8, n_threads, 1)
+    N2 = ns.n_rollout_threads
+    runs = dict(config1_N8_1thread=one(8, 1, 3), config1_N8_allcores=one(8, n_threads, 3),
+                config2_1thread=one(N2, 1, 1), config2_allcores=one(N2, n_threads, 2))
+    head = runs["config2_allcores"]
+    steps = T * N2 * M
+    total = sum(r["seconds_per_iteration"] * (3 if "config1" in k else (1 if "1thread" in k else 2)) for k, r in runs.items())
+    return dict(value=head["agent_steps_per_s"], unit="agent-steps/s", cores=n_threads, kind="port",
+                sample=f"{steps} agent-steps per iteration (T={T} x N={N2} x M={M}, ppo_epoch={ns.ppo_epoch}) of the same workload, "
+                       f"torch-CPU/NumPy oracle (oracle/mappo_oracle.py), 2 iterations on {n_threads} threads = `value`; also 1 thread "
+                       f"and BASELINE configs[0] (N=8) in `runs`; {total:.1f} s of CPU work in all",
+                cpu_model=_cpu_model(), os_cpu_count=os.cpu_count(), runs=runs, seconds=head["seconds_per_iteration"])
 
 
 def main():
     ns = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    from mappo_amd.distributed import shard_threads
+    if ns.scaling == "strong":                              # global thread count fixed: this rank's contiguous share
+        lo, hi = shard_threads(ns.n_rollout_threads, rank, world)
+        ns.local_threads, ns.global_threads = hi - lo, ns.n_rollout_threads
+    else:
+        ns.local_threads, ns.global_threads = ns.n_rollout_threads, ns.n_rollout_threads * world
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     force_dp = os.environ.get("MAPPO_BENCH_FORCE_DP") == "1"     # rehearsal of the data-parallel code path on ONE rank
     result_out = sys.stdout
@@ -262,8 +332,9 @@ def main():
     timer.active = set()
     runner._use_graph, runner.trainer._use_graph = graph_flags
 
-    per_gpu_steps = args.episode_length * args.n_rollout_threads * M
-    value = per_gpu_steps * world * ns.steps / dt
+    per_gpu_steps = args.episode_length * args.n_rollout_threads * M      # this rank's share
+    global_steps = args.episode_length * ns.global_threads * M
+    value = global_steps * ns.steps / dt
     S = per_gpu_steps // args.num_mini_batch                 # samples per update-kernel launch
     H = 64
     macs_critic = D * M * H + H * H + H                     # forward MACs per sample (share_obs 54 -> 64 -> 64 -> 1)
@@ -275,12 +346,10 @@ def main():
         us = kern["actor_critic_update"]
         flops = S * 6 * (macs_critic + macs_actor)
         achieved = flops / (us * 1e-6) / 1e12
-        roofline = dict(bound="mfma", kernel="mlp_update2_dual_kernel<relu, layer_N=1> (actor HEAD 1 + critic HEAD 2 in one launch)",
+        traffic, tnote = measured_traffic("mlp_update16_dual_kernel", S)
+        roofline = dict(bound="mfma", kernel="mlp_update16_dual_kernel<relu, layer_N=1> (actor + critic update in one launch, one wave per 16-sample tile)",
                         achieved=achieved, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS,
-                        traffic=HBM_TRAFFIC_DUAL_UPDATE_BYTES if (S == 76800 and args.num_mini_batch == 1) else None,
-                        traffic_note="HBM bytes per launch = sum of the two networks' single launches measured with rocprofv3 PMC passes "
-                                     "(profiles/r01/g_update_kernels_hbm_pmc.csv): 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE; "
-                                     "the dual launch writes half the slab rows, so its write traffic is at most this",
+                        traffic=traffic, traffic_note=tnote, algorithmic_bytes=S * 4 * ((D * M + D) + (3 + 4 + A)) + 4 * 22678,
                         flops_per_launch=flops, launch_us=us, note=note)
     elif kern.get("critic_update"):
         us = kern["critic_update"]
@@ -288,20 +357,22 @@ def main():
         achieved = flops / (us * 1e-6) / 1e12
         roofline = dict(bound="mfma", kernel="mlp_update2_kernel<relu, layer_N=1, HEAD=critic, wide>", achieved=achieved,
                         peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=achieved / MFMA_F32_PEAK_TFLOPS,
-                        traffic=HBM_TRAFFIC_CRITIC_UPDATE_BYTES if (S == 76800 and args.num_mini_batch == 1) else None,
-                        flops_per_launch=flops, launch_us=us, note=note)
+                        traffic=None, flops_per_launch=flops, launch_us=us, note=note)
     loss_roof = ppo_loss_roofline(runner, timer, A)
+    gae_roof = gae_roofline(runner, timer) if rank == 0 else None
     out = dict(metric="agent-steps/sec (collect+GAE+PPO), MPE simple_spread 3-agent", value=value, unit="agent-steps/s",
                n_gpus=world, steps=ns.steps, warmup=ns.warmup, ms_per_step=1e3 * dt / ns.steps, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               scaling=ns.scaling, vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload="BASELINE configs[1]: MPE simple_spread shape, 3 agents, obs 18 / share_obs 54 / Discrete(5), "
-                                    f"n_rollout_threads={args.n_rollout_threads} per GPU, episode_length={args.episode_length}, "
+                                    f"n_rollout_threads={ns.global_threads} in total ({ns.scaling} scaling: {args.n_rollout_threads} on rank 0 of "
+                                    f"{world}), episode_length={args.episode_length}, "
                                     f"MLP policy (mappo), ppo_epoch={args.ppo_epoch}, num_mini_batch={args.num_mini_batch}, lr 7e-4",
-                           n_rollout_threads_per_gpu=args.n_rollout_threads, episode_length=args.episode_length,
+                           n_rollout_threads_global=ns.global_threads, n_rollout_threads_rank0=args.n_rollout_threads,
+                           episode_length=args.episode_length,
                            num_agents=M, ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch,
-                           agent_steps_per_step=per_gpu_steps * world, parallelism=f"dp{world}",
+                           agent_steps_per_step=global_steps, parallelism=f"dp{world}",
                            exact_minibatch_order=bool(args.exact_minibatch_order), hip_graph=bool(graph_flags[1])),
-               roofline=roofline, ppo_loss_roofline=loss_roof, kernels_us=kern, phase_ms=phase_ms,
+               roofline=roofline, ppo_loss_roofline=loss_roof, gae_roofline=gae_roof, kernels_us=kern, phase_ms=phase_ms,
                last_train_info={k: float(v) for k, v in info.items()})
     if rank == 0:
         if world == 1 and not ns.no_cpu_baseline:

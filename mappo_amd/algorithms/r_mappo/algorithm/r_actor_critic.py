@@ -92,7 +92,8 @@ class R_Actor(_NetBase):
         self.load_state_dict(reference_init_state(args, self.desc.in_dim, action_space.n, "act.action_out.linear",
                                                   args.gain, self._recurrent))
         self._sample_counter = 0
-        self._seed = int(getattr(args, "seed", 1))
+        from mappo_amd.distributed import sampling_seed
+        self._seed = sampling_seed(int(getattr(args, "seed", 1)))       # rank-keyed under data parallelism (parameters are not)
         # device word added to the sampling counter inside the kernel: a captured hipGraph bakes the host counter,
         # so the rollout graph bumps this word once per replay to keep drawing fresh random numbers
         self._counter_dev = torch.zeros(1, dtype=torch.int64, device=self.device_)

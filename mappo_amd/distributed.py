@@ -21,6 +21,17 @@ def shard_threads(n_rollout_threads, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def sampling_seed(seed, rank=None):
+    """Seed of the action-sampling Philox stream of one rank.  Every rank is built with the same `args.seed` so that the
+    replicas' PARAMETERS start identical (torch.manual_seed), but the sampling stream is indexed by the LOCAL row, so an
+    un-keyed seed would give row r of every shard the same uniform at every step — exploration noise perfectly correlated
+    across the shards the gradient all-reduce treats as independent.  The rank is folded into the sampling seed only."""
+    if rank is None:
+        import torch.distributed as dist
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+    return (int(seed) + int(rank) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+
+
 class DataParallel:
     def __init__(self, group=None):
         import torch.distributed as dist

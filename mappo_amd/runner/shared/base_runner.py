@@ -14,6 +14,16 @@ import torch
 from mappo_amd.utils.shared_buffer import SharedReplayBuffer
 
 
+def env_takes_device_actions(envs):
+    """True if `envs.step` may be handed device tensors.  The reference's Dummy/Subproc vec-envs receive NumPy
+    (mpe_runner.py:119, smac_runner.py:34) and do not know about this framework, so the default is NumPy; a device-resident
+    env opts in with `accepts_device_actions = True` (or `graph_safe = True`, which implies it).  `needs_host_actions = True`
+    (round-1 spelling) still forces NumPy."""
+    if getattr(envs, "needs_host_actions", False):
+        return False
+    return bool(getattr(envs, "accepts_device_actions", False) or getattr(envs, "graph_safe", False))
+
+
 def _t2n(x):
     return x.detach().cpu().numpy()
 

@@ -10,7 +10,7 @@ import time
 import numpy as np
 import torch
 
-from .base_runner import Runner, _t2n
+from .base_runner import Runner, _t2n, env_takes_device_actions
 
 
 class MPERunner(Runner):
@@ -152,7 +152,7 @@ class MPERunner(Runner):
             if self._onehot is None:
                 self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
             actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]   # np.eye(n)[actions]
-            if getattr(self.envs, "needs_host_actions", False):
+            if not env_takes_device_actions(self.envs):
                 actions_env = _t2n(actions_env)
         return b.value_preds[step], actions, b.action_log_probs[step], rnn_states, rnn_states_critic, actions_env
 
@@ -164,7 +164,7 @@ class MPERunner(Runner):
         if self._onehot is None:
             self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
         actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]       # np.eye(n)[actions]
-        if getattr(self.envs, "needs_host_actions", False):
+        if not env_takes_device_actions(self.envs):
             actions_env = _t2n(actions_env)
         return actions_env
 
@@ -202,7 +202,7 @@ class MPERunner(Runner):
             self.trainer.prep_rollout()
             action, rnn_states = self.trainer.policy.act(obs.reshape(R, -1), rnn_states, masks, deterministic=True)
             actions_env = eye[action.view(N, self.num_agents)]
-            if getattr(envs, "needs_host_actions", False):
+            if not env_takes_device_actions(envs):
                 actions_env = _t2n(actions_env)
             obs, rewards, dones, _ = envs.step(actions_env)
             obs = torch.as_tensor(obs, dtype=torch.float32).to(self.device)

@@ -10,7 +10,7 @@ from functools import reduce
 import numpy as np
 import torch
 
-from .base_runner import Runner, _t2n
+from .base_runner import Runner, _t2n, env_takes_device_actions
 
 
 class SMACRunner(Runner):
@@ -105,7 +105,7 @@ class SMACRunner(Runner):
         self.trainer.prep_rollout()
         b = self.buffer
         actions, rnn_states, rnn_states_critic = self.trainer.policy.collect_into(b, step, use_available_actions=True)
-        if getattr(self.envs, "needs_host_actions", False):
+        if not env_takes_device_actions(self.envs):
             actions = _t2n(actions)
         return b.value_preds[step], actions, b.action_log_probs[step], rnn_states, rnn_states_critic
 
@@ -167,7 +167,7 @@ class SMACRunner(Runner):
             actions, rnn_states = self.trainer.policy.act(f32(obs).reshape(R, -1), rnn_states, masks, f32(avail).reshape(R, -1),
                                                           deterministic=True)
             actions = actions.view(N, Ma, -1)
-            if getattr(envs, "needs_host_actions", False):
+            if not env_takes_device_actions(envs):
                 actions = _t2n(actions)
             obs, share_obs, rewards, dones, infos, avail = envs.step(actions)
             running += _t2n(f32(rewards)).reshape(N, Ma, 1)

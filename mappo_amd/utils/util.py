@@ -1,5 +1,7 @@
 """Shape / schedule helpers with the reference's names (onpolicy/utils/util.py:9-51,
 onpolicy/algorithms/utils/util.py:15-17).  Spaces are duck-typed by class name, so gym is not needed."""
+import math
+
 import numpy as np
 import torch
 
@@ -45,6 +47,26 @@ def obs_dim_of(space):
     if len(shape) != 1:
         raise NotImplementedError("image observations (CNNBase) are outside this build (SURVEY.md §2.1 #11)")
     return int(shape[0])
+
+
+def get_gard_norm(it):
+    """utils/util.py:9-15 (spelling of the reference kept): L2 norm over the .grad of every parameter that has one."""
+    total = 0.0
+    for p in it:
+        if p.grad is not None:
+            total += float(p.grad.norm()) ** 2
+    return math.sqrt(total)
+
+
+def huber_loss(e, d):
+    """utils/util.py:23-26: e^2/2 inside |e| <= d, d(|e| - d/2) outside (the fused kernels use the same formula)."""
+    inside = (e.abs() <= d).to(e.dtype)
+    return inside * e * e / 2 + (1 - inside) * d * (e.abs() - d / 2)
+
+
+def mse_loss(e):
+    """utils/util.py:28-29"""
+    return e * e / 2
 
 
 def update_linear_schedule(optimizer, epoch, total_num_epochs, initial_lr):

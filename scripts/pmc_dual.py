@@ -25,4 +25,10 @@ slabs = torch.zeros(nd, P, device="cuda"); pda, pdc = ops.update_partials("cuda"
 for _ in range(int(os.environ.get('PMC_N', 6))):
     ops.actor_critic_update(pa, da, obs, pc, dc, sobs, None, B, av, act, olp, adv, active, vold, ret, vn, mom, cfg, slabs, P, 0, col_c, pda, pdc)
 torch.cuda.synchronize()
+# calibration for FETCH_SIZE / WRITE_SIZE (MI355X_MICROARCH.md, HBM section): a streaming copy of a known byte count, 16 B per lane
+if os.environ.get('PMC_CALIB', '1') == '1':
+    src = torch.randn(64 * 1024 * 1024 // 4, device="cuda"); dst = torch.empty_like(src)
+    for _ in range(3):
+        dst.copy_(src)
+    torch.cuda.synchronize()
 print("done")

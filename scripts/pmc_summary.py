@@ -9,7 +9,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
     with open(f, newline="") as fh:
         for r in csv.DictReader(fh):
             name = r["Kernel_Name"]
-            if flt not in name:
+            if flt not in name and not (("FETCH" in r["Counter_Name"] or "WRITE" in r["Counter_Name"]) and "elementwise" in name and "copy" in name.lower()):
                 continue
             short = name.split("(")[0].split("<")[0].split()[-1]
             k = (short, r["Counter_Name"], r.get("VGPR_Count", ""), r.get("LDS_Block_Size", ""))

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: scripts/prof.sh <tag>   (run on the GPU box via gpurun) -> gpurun_out/prof_<tag>/
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
