@@ -530,9 +530,6 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   const float *rawp = Ux + n * D + q * C;                       // flat commit: own features inside the linear [16][D] block
   float *x0p = Ux + n * xs + q * NV;                            // xhat0 [sample][q NV + t]: chunk-major columns (see the epilogue)
 
-#ifdef EXP16_PRIO
-  if (wave >= 4) __builtin_amdgcn_s_setprio(EXP16_PRIO);       // experiment: static priority for the second wave of every SIMD
-#endif
   for (int64_t tile = tile0; tile < n_tiles; tile += tile_stride) {
     const int n_valid = pf.n_valid;
     const bool live = n < n_valid;
@@ -600,9 +597,9 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       }
     }
     STAMP(2);   // layer 1 MFMA
-#ifndef EXP16_PF_LATE
-    prefetch16<HEAD, WIDE>(pf, p, tile + tile_stride, n_tiles, D, C, A, lane, n, q);   // next tile, under this tile's MFMAs
-#endif
+    // next tile, under this tile's MFMAs (issued after the loss instead, the prefetch registers live through the
+    // register-hungry backward pass only — but that is where the pressure peaks: 106 spilled registers, measured)
+    prefetch16<HEAD, WIDE>(pf, p, tile + tile_stride, n_tiles, D, C, A, lane, n, q);
     act_ln_fwd16<RELU>(xh, mean1, rstd1, pos1);
     STAMP(3);   // prefetch issue + act/LN 1
     // ---- hidden layer ----
@@ -683,9 +680,6 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       }
       wave_lds_sync();
     }
-#ifdef EXP16_PF_LATE
-    prefetch16<HEAD, WIDE>(pf, p, tile + tile_stride, n_tiles, D, C, A, lane, n, q);   // next tile, under the backward pass
-#endif
     STAMP(6);   // head + loss (+ head products)
     // ---- backward ----
     if constexpr (LN > 0) {
@@ -714,9 +708,6 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   }
 
   STAMP(12);  // loop exit
-#ifdef EXP16_PRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
   // ---- epilogue.  Raw consumer weights of the transform first: their global loads fly under the reduction ----
   constexpr int NJH = HEAD == 1 ? 2 : 1;
   float ewh[NJH], ew2[LN > 0 ? 8 : 1], ew1[8];

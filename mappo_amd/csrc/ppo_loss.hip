@@ -29,7 +29,7 @@ struct PlArgs {
 };
 
 __global__ __launch_bounds__(PL_BLOCK) void ppo_loss_kernel(PlArgs p) {
-  extern __shared__ __align__(16) float tile[];   // [PL_BLOCK * A]
+  extern __shared__ __align__(16) float tile[];   // [PL_BLOCK * A] logits / d(logits) | [PL_BLOCK * A] availability flags
   __shared__ double smem[16 * 4];
   const int A = p.A;
   const int tid = threadIdx.x;
@@ -48,33 +48,41 @@ __global__ __launch_bounds__(PL_BLOCK) void ppo_loss_kernel(PlArgs p) {
     const int64_t base = tb * PL_BLOCK;
     const int n_here = (int)min((int64_t)PL_BLOCK, p.B - base);
     const int n_el = n_here * A;
-    // ---- stage the logits tile (contiguous in minibatch order) ----
+    // ---- stage the logits tile and (whole-buffer minibatches) the availability tile: both are contiguous [n_here][A]
+    // blocks, fetched as 16-byte-per-lane streams; read per lane as av[a] the flags cost A dword loads with a 4 A-byte lane
+    // stride.  The per-sample scalars are issued before the barrier, so one memory latency covers the whole tile. ----
+    float *atile = tile + PL_BLOCK * A;
+    const bool av_lds = p.avail != nullptr && p.rows == nullptr;
     {
       const float *src = p.logits + base * A;
-      if ((((uintptr_t)src) & 15) == 0) {
+      const float *asrc = av_lds ? p.avail + base * A : src;
+      if ((((uintptr_t)src) & 15) == 0 && (((uintptr_t)asrc) & 15) == 0) {
         const int n4 = n_el >> 2;
-        for (int i = tid; i < n4; i += PL_BLOCK) reinterpret_cast<float4 *>(tile)[i] = reinterpret_cast<const float4 *>(src)[i];
-        for (int i = (n4 << 2) + tid; i < n_el; i += PL_BLOCK) tile[i] = src[i];
+        for (int i = tid; i < n4; i += PL_BLOCK) {
+          const float4 zv = reinterpret_cast<const float4 *>(src)[i];
+          float4 avv = zv;
+          if (av_lds) avv = reinterpret_cast<const float4 *>(asrc)[i];
+          reinterpret_cast<float4 *>(tile)[i] = zv;
+          if (av_lds) reinterpret_cast<float4 *>(atile)[i] = avv;
+        }
+        for (int i = (n4 << 2) + tid; i < n_el; i += PL_BLOCK) { tile[i] = src[i]; if (av_lds) atile[i] = asrc[i]; }
       } else {
-        for (int i = tid; i < n_el; i += PL_BLOCK) tile[i] = src[i];
+        for (int i = tid; i < n_el; i += PL_BLOCK) { tile[i] = src[i]; if (av_lds) atile[i] = asrc[i]; }
       }
     }
+    const bool mine = tid < n_here;
+    const int64_t i = base + (mine ? tid : 0);
+    const int64_t row = p.rows ? (int64_t)p.rows[i] : i;
+    const float f_act = p.actions[row], old_lp = p.old_logp[row], adv = p.adv[row], active = p.active[row], v = p.values[i],
+                vo = p.v_old[row], ret = p.returns[row];
     __syncthreads();
-    if (tid < n_here) {
-      const int64_t i = base + tid;
-      const int64_t row = p.rows ? (int64_t)p.rows[i] : i;
+    if (mine) {
       float *z = tile + tid * A;
-      const int act = (int)p.actions[row];
-      const float old_lp = p.old_logp[row];
-      const float adv = p.adv[row];
-      const float active = p.active[row];
-      const float v = p.values[i];
-      const float vo = p.v_old[row];
-      const float ret = p.returns[row];
+      const int act = (int)f_act;
       // ---- pass 1: availability mask (distributions.py:66-67) + max ----
       uint32_t dead = 0u;
       float zmax = -FLT_MAX;
-      const float *av = p.avail ? p.avail + row * A : nullptr;
+      const float *av = p.avail ? (av_lds ? atile + tid * A : p.avail + row * A) : nullptr;
       for (int a = 0; a < A; ++a) {
         float za = z[a];
         if (av && av[a] == 0.f) { za = -1e10f; dead |= (1u << a); z[a] = za; }
@@ -224,7 +232,7 @@ extern "C" int mappo_ppo_loss_fwd_bwd(const float *logits, const float *values, 
   p.adv = adv; p.active = active; p.v_old = v_old; p.returns = returns; p.vn_state = vn_state; p.mb_moments = mb_moments;
   p.dlogits = dlogits; p.dvalues = dvalues; p.partials = (double *)workspace; p.cfg = *cfg; p.B = B; p.A = A;
   const int nblk = pl_blocks(B);
-  const size_t lds = (size_t)PL_BLOCK * A * sizeof(float);
+  const size_t lds = (size_t)2 * PL_BLOCK * A * sizeof(float);      // logits / d(logits) tile + availability tile
   PROF_LAUNCH(MAPPO_PROF_PPO_LOSS, ppo_loss_kernel, dim3(nblk), dim3(PL_BLOCK), lds, as_stream(stream), p);
   hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(PL_BLOCK), 0, as_stream(stream), (const double *)workspace, nblk,
                      mb_moments, B, cfg->use_policy_active_masks, cfg->use_value_active_masks, stats);
