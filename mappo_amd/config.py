@@ -89,6 +89,10 @@ def get_config():
     p.add_argument("--use_hip_graph", **off,
                    help="by default the launch-bound inner loops (PPO updates; rollout with a graph-safe env) are captured "
                         "into hipGraphs after one eager pass; pass the flag to always launch eagerly")
+    p.add_argument("--host_staging", **off,
+                   help="by default the NumPy output of a CPU vec-env goes through pinned double-buffered staging blocks "
+                        "(mappo_amd/utils/host_staging.py) and feeds the same one-launch rollout step as a device env; pass the "
+                        "flag to upload with plain torch copies")
     p.add_argument("--fuse_rollout_step", **off,
                    help="by default an MLP policy's rollout step (insert of the previous env output + get_actions + get_values) "
                         "is ONE kernel launch (mappo_rollout_step); pass the flag to use the separate insert / actor / critic launches")

@@ -23,6 +23,11 @@ class MPERunner(Runner):
         # the rollout has no collective in it, so data-parallel ranks capture it too
         self._use_graph = bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False))
         self._dist_present = config.get("dist_group") is not None
+        # CPU vec-envs: pinned double-buffered staging, so that their NumPy output feeds the same one-launch step
+        self._staging, self._eye_np = None, None
+        if not env_takes_device_actions(self.envs) and bool(getattr(self.all_args, "host_staging", True)):
+            from mappo_amd.utils.host_staging import HostStaging
+            self._staging = HostStaging(self.device)
 
     def run(self):
         self.warmup()
@@ -72,14 +77,19 @@ class MPERunner(Runner):
                     actions = self.trainer.policy.collect_step_fused(self.buffer, step, None, self.use_centralized_V)
                 elif pending is not None:
                     self.buffer.step = step % self.episode_length
+                if self._staging is not None:
+                    self._staging.consumed()                # the launch above read the previous upload
                 actions_env = self._actions_env(actions)
                 obs, rewards, dones, infos = self.envs.step(actions_env)
-                pending = (obs, rewards, dones)
+                pending = self._stage(obs, rewards, dones)
                 continue
             values, actions, action_log_probs, rnn_states, rnn_states_critic, actions_env = self.collect(step)
             obs, rewards, dones, infos = self.envs.step(actions_env)
+            obs, rewards, dones = self._stage(obs, rewards, dones)
             data = obs, rewards, dones, infos, values, actions, action_log_probs, rnn_states, rnn_states_critic
             self.insert(data)
+            if self._staging is not None:
+                self._staging.consumed()
         if fuse:
             # the last env output: its insert + the bootstrap value of compute() in one launch (critic workgroups + insert)
             b = self.buffer
@@ -87,6 +97,8 @@ class MPERunner(Runner):
                 self._next_values = torch.empty(b.n_rollout_threads * b.num_agents, device=b.device)
             nv = self.trainer.policy.collect_step_fused(b, self.episode_length, pending, self.use_centralized_V,
                                                         values_only=self._next_values)
+            if self._staging is not None:
+                self._staging.consumed()
             if nv is None:
                 self.insert(pending + (None,) * 6)
                 self.compute()
@@ -148,24 +160,49 @@ class MPERunner(Runner):
         b = self.buffer
         actions, rnn_states, rnn_states_critic = self.trainer.policy.collect_into(b, step)
         actions_env = None
-        if getattr(self.envs, "consumes_actions", True):        # synthetic envs ignore the actions: skip the one-hot
+        if getattr(self.envs, "consumes_actions", True) and self._staging is not None:
+            actions_env = self._host_onehot(actions)
+        elif getattr(self.envs, "consumes_actions", True):      # synthetic envs ignore the actions: skip the one-hot
             if self._onehot is None:
                 self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
             actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]   # np.eye(n)[actions]
             if not env_takes_device_actions(self.envs):
-                actions_env = _t2n(actions_env)
+                actions_env = self._host_actions(actions_env)
         return b.value_preds[step], actions, b.action_log_probs[step], rnn_states, rnn_states_critic, actions_env
+
+    def _stage(self, obs, rewards, dones):
+        """Env output -> what the fused step / insert kernels read.  Host arrays go through the pinned staging blocks."""
+        if self._staging is None:
+            return obs, rewards, dones
+        d = self._staging.upload(obs=obs, rewards=rewards, dones=np.asarray(dones, dtype=np.bool_) if not torch.is_tensor(dones) else dones)
+        return d["obs"], d["rewards"], d["dones"]
+
+    def _host_actions(self, actions_env):
+        if self._staging is not None:
+            return self._staging.download("actions_env", actions_env)
+        return _t2n(actions_env)
+
+    def _host_onehot(self, actions):
+        """One-hot env actions for a CPU env (mpe_runner.py:119, `np.eye(n)[actions]`): the integer actions come down through
+        pinned memory (N x M floats instead of N x M x n) and the one-hot is built on the host, as the reference builds it."""
+        b = self.buffer
+        a = self._staging.download("actions", actions.view(b.n_rollout_threads, b.num_agents))
+        if self._eye_np is None:
+            self._eye_np = np.eye(self.envs.action_space[0].n, dtype=np.float32)
+        return self._eye_np[a.astype(np.int64)]
 
     # mpe_runner.py:125-139
     def _actions_env(self, actions):
         b = self.buffer
         if not getattr(self.envs, "consumes_actions", True):     # synthetic envs ignore the actions: skip the one-hot
             return None
+        if self._staging is not None:
+            return self._host_onehot(actions)
         if self._onehot is None:
             self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
         actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]       # np.eye(n)[actions]
         if not env_takes_device_actions(self.envs):
-            actions_env = _t2n(actions_env)
+            actions_env = self._host_actions(actions_env)
         return actions_env
 
     def insert(self, data):

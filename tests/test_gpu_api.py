@@ -254,3 +254,70 @@ def test_naive_recurrent_train_vs_oracle(gpu_device, use_graph):
             close(v, opol.critic.state_dict()[k].numpy(), 1e-4, 8e-6, f"iteration {it}: {k}")
     if use_graph:
         assert any(isinstance(g, torch.cuda.CUDAGraph) for g in tr._graphs.values())
+
+
+class PoolEnv:
+    """Replays pre-drawn observations / rewards (independent of the actions): once as a CPU vec-env (NumPy in and out), once as
+    a device-resident env (tensors in and out).  Same data, so the two rollouts must fill the buffer identically."""
+
+    def __init__(self, obs, rew, T, A, device=None):
+        self.T, self.t = T, 0
+        self.N, self.M, self.D = obs.shape[1:]
+        self.on_device = device is not None
+        if self.on_device:
+            self.accepts_device_actions = True
+            self.obs, self.rew = torch.from_numpy(obs).to(device), torch.from_numpy(rew).to(device)
+        else:
+            self.obs, self.rew = obs, rew
+        self.observation_space = [Box(self.D)] * self.M
+        self.share_observation_space = [Box(self.D * self.M)] * self.M
+        self.action_space = [Discrete(A)] * self.M
+        self.received = []
+
+    def reset(self):
+        self.t = 0
+        return self.obs[0]
+
+    def step(self, actions_env):
+        assert torch.is_tensor(actions_env) == self.on_device
+        self.received.append(actions_env.cpu().numpy().copy() if self.on_device else actions_env.copy())
+        self.t += 1
+        dones = np.full((self.N, self.M), self.t % self.T == 0)
+        if self.on_device:
+            dones = torch.from_numpy(dones).to(self.obs.device)
+        return self.obs[self.t], self.rew[self.t], dones, None
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_host_env_staging_equals_device_env(gpu_device, fuse):
+    """a NumPy vec-env through the pinned double-buffered staging (mappo_amd/utils/host_staging.py) fills the
+    buffer exactly as a device-resident env with the same data does, step by step, and trains to the same statistics —
+    for the one-launch rollout step and for the separate insert / collect launches."""
+    from mappo_amd.config import get_config
+    from mappo_amd.runner.shared.mpe_runner import MPERunner
+    T, N, Ma, D, A = 25, 16, 3, 18, 5
+    rng = np.random.default_rng(9)
+    obs = rng.standard_normal((2 * T + 2, N, Ma, D)).astype(np.float32)
+    rew = np.repeat(rng.standard_normal((2 * T + 2, N, 1, 1)).astype(np.float32), Ma, axis=2)
+    out = []
+    for device in (None, torch.device("cuda:0")):
+        a = _args(get_config, episode_length=T, n_rollout_threads=N, ppo_epoch=2, lr=7e-4, critic_lr=7e-4, seed=1, env_name="MPE",
+                  use_hip_graph=False)
+        a.fuse_rollout_step = fuse
+        torch.manual_seed(1)
+        env = PoolEnv(obs, rew, T, A, device)
+        r = MPERunner(dict(all_args=a, envs=env, eval_envs=None, num_agents=Ma, device=torch.device("cuda:0"), run_dir=None))
+        assert (r._staging is not None) == (device is None)
+        r.warmup()
+        infos = [r.run_episode()[0], r.run_episode()[0]]            # two episodes: the staging slots wrap around many times
+        b = r.buffer
+        out.append(({n: getattr(b, n).cpu().numpy().copy() for n in BUF_NAMES}, infos, np.stack(env.received),
+                    r.policy.flat_params.cpu().numpy().copy()))
+    (b0, i0, a0, p0), (b1, i1, a1, p1) = out
+    np.testing.assert_array_equal(a0, a1, err_msg="actions handed to the envs")
+    for n in BUF_NAMES:
+        np.testing.assert_array_equal(b0[n], b1[n], err_msg=n)
+    for x, y in zip(i0, i1):
+        for k in x:
+            assert x[k] == y[k], k
+    np.testing.assert_array_equal(p0, p1)
