@@ -126,6 +126,9 @@ def parse():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong (default): n_rollout_threads is the GLOBAL count, sharded over the ranks (north_star's >= 6x at "
                          "8 GPUs is a strong-scaling target); weak: n_rollout_threads per GPU")
+    ap.add_argument("--env", choices=("synthetic", "mpe"), default="synthetic",
+                    help="synthetic (default, BASELINE.json: MPE-shaped N(0,1) observations) | mpe: the GPU-vectorised simple_spread "
+                         "environment (mappo_amd/envs/mpe_spread.py: real dynamics, rewards and resets, still no process boundary)")
     ap.add_argument("--episode_length", type=int, default=25)
     ap.add_argument("--ppo_epoch", type=int, default=10)
     ap.add_argument("--num_mini_batch", type=int, default=1)
@@ -280,7 +283,11 @@ def main():
     args = make_args(ns)
     M, D, A = 3, 18, 5
     torch.manual_seed(args.seed)                           # identical initial replicas on every rank
-    env = SyntheticMPEEnv(args.n_rollout_threads, M, D, A, args.episode_length, seed=1 + rank, device=device)
+    if ns.env == "mpe":
+        from mappo_amd.envs.mpe_spread import SimpleSpreadVecEnv
+        env = SimpleSpreadVecEnv(args.n_rollout_threads, M, 3, args.episode_length, seed=1 + rank, device=device)
+    else:
+        env = SyntheticMPEEnv(args.n_rollout_threads, M, D, A, args.episode_length, seed=1 + rank, device=device)
     dp = DataParallel() if (world > 1 or force_dp) else None
     runner = MPERunner(dict(all_args=args, envs=env, eval_envs=None, num_agents=M, device=device, run_dir=None, dist_group=dp))
     timer = KernelTimer()
@@ -362,11 +369,12 @@ def main():
     gae_roof = gae_roofline(runner, timer) if rank == 0 else None
     out = dict(metric="agent-steps/sec (collect+GAE+PPO), MPE simple_spread 3-agent", value=value, unit="agent-steps/s",
                n_gpus=world, steps=ns.steps, warmup=ns.warmup, ms_per_step=1e3 * dt / ns.steps, higher_is_better=True,
-               scaling=ns.scaling, vs_baseline=None, dtype="f32", data="synthetic",
+               scaling=ns.scaling, vs_baseline=None, dtype="f32",
+               data="synthetic" if ns.env == "synthetic" else "MPE simple_spread dynamics on the GPU (mappo_amd/envs/mpe_spread.py), random-init weights",
                config=dict(workload="BASELINE configs[1]: MPE simple_spread shape, 3 agents, obs 18 / share_obs 54 / Discrete(5), "
                                     f"n_rollout_threads={ns.global_threads} in total ({ns.scaling} scaling: {args.n_rollout_threads} on rank 0 of "
                                     f"{world}), episode_length={args.episode_length}, "
-                                    f"MLP policy (mappo), ppo_epoch={args.ppo_epoch}, num_mini_batch={args.num_mini_batch}, lr 7e-4",
+                                    f"MLP policy (mappo), ppo_epoch={args.ppo_epoch}, num_mini_batch={args.num_mini_batch}, lr 7e-4, env={ns.env}",
                            n_rollout_threads_global=ns.global_threads, n_rollout_threads_rank0=args.n_rollout_threads,
                            episode_length=args.episode_length,
                            num_agents=M, ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch,

@@ -331,6 +331,20 @@ int mappo_reduce_clip_adam(const float *slabs, int32_t n_slabs, int64_t slab_str
                            const float *opt_hyper, int32_t *opt_step, float *grad_norms, double *norm_acc /*or NULL*/,
                            void *workspace, mappo_stream_t stream);
 
+/* GPU-vectorised MPE simple_spread (csrc/mpe_env.hip): N environments x M agents x L landmarks, one launch per
+ * step.  Replaces World.step / Scenario.reward / Scenario.observation / MultiAgentEnv.step + the vec-env's reset-on-done
+ * (onpolicy/envs/mpe/core.py:207-322, scenarios/simple_spread.py:32-103, environment.py:117-256, env_wrappers.py:146-152).
+ * State is caller-owned device memory: agent_pos / agent_vel [N][M][2] and landmark_pos [N][L][2] in float64 (the reference's
+ * NumPy dtype), tstep [N] int32, episode [N] int64 (reset counter = Philox counter).  Outputs: obs [N][M][4+2L+4(M-1)] fp32,
+ * rewards [N][M] fp32 (shared reward), dones [N][M] bool bytes.  action_mode 0: actions = the reference's actions_env
+ * [N][M][5] (one-hot); 1: action indices [N][M] as fp32 (the buffer's own format).  An environment whose episode ends is
+ * reset inside the same launch and returns the reset observation, as DummyVecEnv / SubprocVecEnv do. */
+int mappo_mpe_spread_reset(double *agent_pos, double *agent_vel, double *landmark_pos, int32_t *tstep, int64_t *episode, float *obs,
+                           int32_t N, int32_t M, int32_t L, uint64_t seed, mappo_stream_t stream);
+int mappo_mpe_spread_step(double *agent_pos, double *agent_vel, double *landmark_pos, int32_t *tstep, int64_t *episode,
+                          const float *actions, int32_t action_mode, float *obs, float *rewards, uint8_t *dones, int32_t N, int32_t M,
+                          int32_t L, int32_t episode_length, uint64_t seed, mappo_stream_t stream);
+
 /* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel carries the two hipEvent_t
  * handles (hipExtLaunchKernelGGL: start / stop of that dispatch on its own stream); the hook disarms after one use. */
 #define MAPPO_PROF_GAE 0

@@ -459,3 +459,22 @@ def profile_arm(kernel, start_event, stop_event):
             ev.record()
     rc = _lib.load().mappo_profile_arm(PROF_IDS[kernel], C.c_void_p(start_event.cuda_event), C.c_void_p(stop_event.cuda_event))
     _lib.check(rc, "mappo_profile_arm")
+
+
+# ---- GPU-vectorised MPE simple_spread (csrc/mpe_env.hip) -------------------------------------------------------------
+def mpe_spread_reset(agent_pos, agent_vel, landmark_pos, tstep, episode, obs, N, M, L, seed):
+    f64 = torch.float64
+    rc = _lib.load().mappo_mpe_spread_reset(_ptr(agent_pos, f64), _ptr(agent_vel, f64), _ptr(landmark_pos, f64), _ptr(tstep, torch.int32),
+                                            _ptr(episode, torch.int64), _ptr(obs),
+                                            int(N), int(M), int(L), int(seed) & (2 ** 64 - 1), _stream())
+    _lib.check(rc, "mappo_mpe_spread_reset")
+
+
+def mpe_spread_step(agent_pos, agent_vel, landmark_pos, tstep, episode, actions, action_mode, obs, rewards, dones, N, M, L,
+                    episode_length, seed):
+    f64 = torch.float64
+    rc = _lib.load().mappo_mpe_spread_step(_ptr(agent_pos, f64), _ptr(agent_vel, f64), _ptr(landmark_pos, f64), _ptr(tstep, torch.int32),
+                                           _ptr(episode, torch.int64), _ptr(actions), int(action_mode), _ptr(obs), _ptr(rewards),
+                                           _ptr(dones, torch.uint8), int(N), int(M), int(L),
+                                           int(episode_length), int(seed) & (2 ** 64 - 1), _stream())
+    _lib.check(rc, "mappo_mpe_spread_step")

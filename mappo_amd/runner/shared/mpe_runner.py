@@ -162,6 +162,8 @@ class MPERunner(Runner):
         actions_env = None
         if getattr(self.envs, "consumes_actions", True) and self._staging is not None:
             actions_env = self._host_onehot(actions)
+        elif getattr(self.envs, "consumes_actions", True) and getattr(self.envs, "accepts_index_actions", False):
+            actions_env = actions
         elif getattr(self.envs, "consumes_actions", True):      # synthetic envs ignore the actions: skip the one-hot
             if self._onehot is None:
                 self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
@@ -198,6 +200,8 @@ class MPERunner(Runner):
             return None
         if self._staging is not None:
             return self._host_onehot(actions)
+        if getattr(self.envs, "accepts_index_actions", False):   # device env that decodes the buffer's action indices itself
+            return actions
         if self._onehot is None:
             self._onehot = torch.eye(self.envs.action_space[0].n, device=b.device)
         actions_env = self._onehot[actions.view(b.n_rollout_threads, b.num_agents).long()]       # np.eye(n)[actions]
