@@ -23,6 +23,9 @@ _ALIASES = {
     "onpolicy.runner.shared.base_runner": "mappo_amd.runner.shared.base_runner",
     "onpolicy.runner.shared.mpe_runner": "mappo_amd.runner.shared.mpe_runner",
     "onpolicy.runner.shared.smac_runner": "mappo_amd.runner.shared.smac_runner",
+    "onpolicy.utils.separated_buffer": "mappo_amd.utils.separated_buffer",
+    "onpolicy.runner.separated.base_runner": "mappo_amd.runner.separated.base_runner",
+    "onpolicy.runner.separated.mpe_runner": "mappo_amd.runner.separated.mpe_runner",
 }
 
 

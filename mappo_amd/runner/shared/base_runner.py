@@ -91,6 +91,10 @@ class Runner(object):
             self.save_dir = os.path.join(str(self.run_dir), "models")
             os.makedirs(self.save_dir, exist_ok=True)
 
+        self._build(config)
+
+    def _build(self, config):
+        """Policy, trainer and buffer (base_runner.py:70-89); the separated runner overrides this with per-agent lists."""
         from mappo_amd.algorithms.r_mappo.r_mappo import R_MAPPO as TrainAlgo
         from mappo_amd.algorithms.r_mappo.algorithm.rMAPPOPolicy import R_MAPPOPolicy as Policy
 

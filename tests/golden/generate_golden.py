@@ -446,13 +446,92 @@ def gen_train():
     save("train", **out)
 
 
+def gen_separated():
+    """share_policy=False: the reference's SeparatedReplayBuffer (onpolicy/utils/separated_buffer.py:13-393) — one buffer,
+    policy and trainer per agent (runner/separated/base_runner.py:70-132).  Slot semantics incl. the step wrap, after_update,
+    compute_returns, the feed-forward generator, and R_MAPPO.train on such a buffer."""
+    from onpolicy.utils.separated_buffer import SeparatedReplayBuffer
+    rng = np.random.default_rng(900)
+    f = np.float32
+    out = {}
+    # (1) insert / after_update
+    T, N = 4, 3
+    a = make_args(episode_length=T, n_rollout_threads=N, hidden_size=8)
+    buf = SeparatedReplayBuffer(a, [6], [18], Discrete(5))
+    names = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "value_preds", "returns", "available_actions", "actions",
+             "action_log_probs", "rewards", "masks", "bad_masks", "active_masks")
+    arrs = lambda pre, b: {f"{pre}/{n}": getattr(b, n).copy() for n in names}
+    for s_ in range(T + 2):
+        d = dict(share_obs=rng.standard_normal((N, 18)).astype(f), obs=rng.standard_normal((N, 6)).astype(f),
+                 rnn_a=rng.standard_normal((N, 1, 8)).astype(f), rnn_c=rng.standard_normal((N, 1, 8)).astype(f),
+                 actions=rng.integers(0, 5, (N, 1)).astype(f), logp=rng.standard_normal((N, 1)).astype(f),
+                 values=rng.standard_normal((N, 1)).astype(f), rewards=rng.standard_normal((N, 1)).astype(f),
+                 masks=(rng.random((N, 1)) > 0.3).astype(f), bad=(rng.random((N, 1)) > 0.3).astype(f),
+                 active=(rng.random((N, 1)) > 0.3).astype(f), avail=(rng.random((N, 5)) > 0.3).astype(f))
+        for k, v in d.items():
+            out[f"ins/in{s_}/{k}"] = v
+        buf.insert(d["share_obs"], d["obs"], d["rnn_a"], d["rnn_c"], d["actions"], d["logp"], d["values"], d["rewards"], d["masks"],
+                   d["bad"], d["active"], d["avail"])
+        out[f"ins/step_after{s_}"] = np.array(buf.step)
+        if s_ == T - 1:
+            out.update(arrs("ins/full", buf))
+            buf.after_update()
+            out.update(arrs("ins/after_update", buf))
+    out.update(arrs("ins/final", buf))
+    out["ins/n_inserts"] = np.array(T + 2)
+    # (2) compute_returns (GAE + ValueNorm, the default flags) and the feed-forward generator, (3) train()
+    T, N, D, S, A = 8, 6, 18, 54, 5
+    torch.manual_seed(901)
+    a = make_args(episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=2, num_mini_batch=2)
+    pol = R_MAPPOPolicy(a, [D], [S], Discrete(A))
+    tr = R_MAPPO(a, pol)
+    buf = SeparatedReplayBuffer(a, [D], [S], Discrete(A))
+    for n in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "value_preds", "rewards", "action_log_probs"):
+        arr = getattr(buf, n); arr[...] = rng.standard_normal(arr.shape).astype(f)
+    buf.action_log_probs[...] = -np.abs(buf.action_log_probs) - 0.5
+    buf.value_preds[...] *= 0.3
+    buf.actions[...] = rng.integers(0, A, buf.actions.shape).astype(f)
+    buf.masks[...] = (rng.random(buf.masks.shape) > 0.15).astype(f)
+    buf.active_masks[...] = (rng.random(buf.masks.shape) > 0.2).astype(f)
+    nv = rng.standard_normal((N, 1)).astype(f)
+    buf.compute_returns(nv, tr.value_normalizer)
+    out["tr/dims"] = np.array([T, N, D, S, A, a.ppo_epoch, a.num_mini_batch])
+    out["tr/next_value"] = nv
+    out.update(arrs("tr/buf", buf))
+    adv = (buf.returns[:-1] - tr.value_normalizer.denormalize(buf.value_preds[:-1])).astype(f)
+    torch.manual_seed(55)
+    rand = torch.randperm(T * N).numpy()
+    torch.manual_seed(55)
+    batches = list(buf.feed_forward_generator(adv, 2))
+    out["gen/rand"] = rand
+    out["gen/adv"] = adv
+    tuple_names = ("share_obs", "obs", "rnn_states", "rnn_states_critic", "actions", "value_preds", "returns", "masks", "active_masks",
+                   "old_action_log_probs", "adv_targ", "available_actions")
+    for bi, sample in enumerate(batches):
+        for nm, arr in zip(tuple_names, sample):
+            out[f"gen/b{bi}/{nm}"] = np.asarray(arr)
+    out["gen/n_batches"] = np.array(len(batches))
+    out.update(sd_arrays("tr/actor0", pol.actor)); out.update(sd_arrays("tr/critic0", pol.critic))
+    torch.manual_seed(3900)
+    perms = [torch.randperm(T * N).numpy() for _ in range(a.ppo_epoch)]
+    torch.manual_seed(3900)
+    tr.prep_training()
+    info = tr.train(buf)
+    out["tr/perms"] = np.stack(perms)
+    out["tr/info_keys"] = np.array(list(info.keys()))
+    out["tr/info"] = np.array([float(v) for v in info.values()], dtype=np.float64)
+    out.update(sd_arrays("tr/actor1", pol.actor)); out.update(sd_arrays("tr/critic1", pol.critic))
+    out["tr/vn1"] = vn_state(tr.value_normalizer)
+    save("separated", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
     ns = ap.parse_args()
     torch.set_num_threads(1)
     gens = dict(valuenorm=gen_valuenorm, gae=gen_gae, advnorm=gen_advnorm, generators=gen_generators,
-                insert=gen_insert, forward=gen_forward, ppo_update=gen_ppo_update, train=gen_train)
+                insert=gen_insert, forward=gen_forward, ppo_update=gen_ppo_update, train=gen_train, separated=gen_separated)
     for k, fn in gens.items():
         if ns.only in (None, k):
             fn()

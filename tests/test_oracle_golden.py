@@ -277,3 +277,33 @@ def test_clip_adam_closed_form_matches_torch():
         opt.step()
         p, m, v, n = O.clip_adam_ref(p, gr, m, v, step, 7e-4, 10.0)
         close(n, n_t, 1e-6); close(p, param.detach().numpy(), 1e-6, 1e-7)
+
+
+def test_separated_buffer_train_matches_reference():
+    """share_policy=False (golden/separated.npz from onpolicy/utils/separated_buffer.py + r_mappo.py): the reference's separated
+    buffer is the oracle's shared buffer with ONE agent — returns and a whole train() agree with the reference's outputs."""
+    g = golden("separated")
+    T, N, D, S, A, epochs, nmb = [int(x) for x in g["tr/dims"]]
+    a = args_from(episode_length=T, n_rollout_threads=N, lr=7e-4, critic_lr=7e-4, ppo_epoch=epochs, num_mini_batch=nmb)
+    pol = O.PolicyRef(a, D, S, A)
+    load_net(pol.actor, g, "tr/actor0"); load_net(pol.critic, g, "tr/critic0")
+    d = sub(g, "tr/buf")
+    buf = O.BufferRef(a, 1, D, S, A)
+    for name in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "value_preds", "returns", "available_actions", "actions",
+                 "action_log_probs", "rewards", "masks", "bad_masks", "active_masks"):
+        getattr(buf, name)[...] = np.expand_dims(d[name], 2)
+    want = buf.returns.copy()
+    buf.returns[...] = 0
+    vn = O.ValueNormRef()
+    buf.compute_returns(g["tr/next_value"][:, None, :], vn)
+    close(buf.returns[:T], want[:T], 1e-5, 1e-6)
+    buf.returns[...] = want
+    info = O.train_ref(a, pol, vn, buf, perms=list(g["tr/perms"]))
+    ref = dict(zip([str(k) for k in g["tr/info_keys"]], g["tr/info"]))
+    for k, v in info.items():
+        close(v, ref[k], 1e-4)
+    for tag, net in (("actor1", pol.actor), ("critic1", pol.critic)):
+        ref_sd = sub(g, f"tr/{tag}")
+        for k, v in net.state_dict().items():
+            close(v.numpy(), ref_sd[k], 1e-4, 1e-6)
+    close(vn.state(), g["tr/vn1"], 1e-6)
