@@ -1283,6 +1283,7 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
 
 #include "mlp_upd2.h"
 #include "mlp_upd16.h"
+#include "mlp_wide16.h"
 
 #define LDS_LIMIT (160 * 1024)
 #define LDS_STATIC 1024                      // static __shared__ of the kernels (reduction scratch), rounded up
@@ -1306,6 +1307,9 @@ template <bool R, int L>
 int upd16_inst(int head, bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a);
 template <bool R, int L>
 int upd16d_inst(bool wide_a, bool wide_c, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Dual16Args &d);
+// the same network from the layer-1 pre-activations on (in_dim 65..512; layer 1 in mlp_wide16.h / wide_l1_bwd_kernel)
+template <bool R, int L>
+int upd16x_inst(int head, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a);
 
 #ifdef MLP_TU_UPD
 template <bool R, int L, int HEAD, int W>
@@ -1413,6 +1417,24 @@ int upd16d_inst(bool wa, bool wc, dim3 grid, dim3 block, size_t lds_bytes, hipSt
   return wc ? upd16d_launch<R, L, false, true>(grid, block, lds_bytes, st, d) : upd16d_launch<R, L, false, false>(grid, block, lds_bytes, st, d);
 }
 template int upd16d_inst<MLP_UPD_RELU, MLP_UPD_LN>(bool, bool, dim3, dim3, size_t, hipStream_t, const Dual16Args &);
+
+template <bool R, int L, int HEAD>
+static int upd16x_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16x_kernel<R, L, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)UPD16_LDS_MAX);
+    if (e_ != hipSuccess) { mappo_set_error("update16x: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update16x_kernel<R, L, HEAD>), grid, block, lds_bytes, st, a);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+int upd16x_inst(int head, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
+  return head == 1 ? upd16x_launch<R, L, 1>(grid, block, lds_bytes, st, a) : upd16x_launch<R, L, 2>(grid, block, lds_bytes, st, a);
+}
+template int upd16x_inst<MLP_UPD_RELU, MLP_UPD_LN>(int, dim3, dim3, size_t, hipStream_t, const Upd16Args &);
 #endif
 
 #if defined(MLP_TU_MAIN) || defined(MLP_TU_STEP)
@@ -1710,6 +1732,43 @@ static int prep16(Upd16Args &a, bool actor, const char *who) {
   a.zero_row0 = a.zero_row1 = 0; a.zero_col0 = 0; a.zero_cols = 0; a.zero_partials = nullptr;
   return MAPPO_OK;
 }
+// ---- wide inputs through the 16-sample-tile kernels ----
+static bool upd16x_eligible(const mappo_net_desc &d, bool actor) {
+  const char *e = getenv("MAPPO_UPD16");
+  if (e && e[0] == '0') return false;
+  return d.in_dim > MAXD && d.in_dim <= 512 && d.layer_N <= 1 && !d.recurrent && (actor ? d.out_dim <= 16 : d.out_dim == 1);
+}
+static int64_t wide_z1_offset(int64_t B) { return ((int64_t)(HID + 2) * B + 3) & ~(int64_t)3; }     // dz1 [64][B] | mean0 | rstd0 | (pad) | z1 [B][64]
+static size_t upd16x_lds_floats(const mappo_net_desc &d, bool actor) {
+  if (actor) return d.layer_N > 0 ? L16<1, 1, true, true>::TOTAL : L16<0, 1, true, true>::TOTAL;
+  return d.layer_N > 0 ? L16<1, 2, true, true>::TOTAL : L16<0, 2, true, true>::TOTAL;
+}
+static int prep16x(Upd16Args &a, bool actor, const char *who) {
+  UpdArgs &u = a.u;
+  u.off = net_offsets(u.desc);
+  MAPPO_REQUIRE(u.slab_col0 >= 0 && u.slab_col0 + u.off.total <= u.slab_stride, "%s: slab column range", who);
+  MAPPO_REQUIRE(upd16x_lds_floats(u.desc, actor) * sizeof(float) <= UPD16_LDS_MAX, "%s: needs %zu B of LDS", who,
+                upd16x_lds_floats(u.desc, actor) * sizeof(float));
+  a.zero_row0 = a.zero_row1 = 0; a.zero_col0 = 0; a.zero_cols = 0; a.zero_partials = nullptr;
+  return MAPPO_OK;
+}
+// z1 = b1' + W1' xhat0 and the row statistics, one launch (mlp_wide16.h)
+static int launch_wide_l1_fwd(const float *params, const mappo_net_desc &d, const NetOff &o, const float *x, const int32_t *rows, int64_t B,
+                              float *z1, float *mean0, float *rstd0, hipStream_t st, const char *who) {
+  Wide16Args w = {};
+  w.params = params; w.x = x; w.rows = rows; w.z1 = z1; w.mean0 = mean0; w.rstd0 = rstd0; w.B = B; w.D = d.in_dim;
+  w.w1 = o.w1; w.b1 = o.b1; w.fn_w = d.use_feature_norm ? o.fn_w : -1; w.fn_b = d.use_feature_norm ? o.fn_b : -1;
+  const int64_t n_groups = ((B + 15) / 16 + 7) / 8;
+  dim3 grid((unsigned)(n_groups < NUM_CU ? n_groups : NUM_CU)), block(512);
+  const int nch = (d.in_dim + 63) / 64;
+  if (nch <= 2) hipLaunchKernelGGL((wide_l1_fwd16_kernel<2>), grid, block, 0, st, w);
+  else if (nch <= 4) hipLaunchKernelGGL((wide_l1_fwd16_kernel<4>), grid, block, 0, st, w);
+  else if (nch <= 6) hipLaunchKernelGGL((wide_l1_fwd16_kernel<6>), grid, block, 0, st, w);
+  else hipLaunchKernelGGL((wide_l1_fwd16_kernel<8>), grid, block, 0, st, w);
+  MAPPO_CHECK_LAUNCH(who);
+  return MAPPO_OK;
+}
+
 // workgroups of the dual launch: the chip's 256 CUs split by the networks' tile costs (few tiles: one tile per wave)
 static void upd16_split(const mappo_net_desc &da, const mappo_net_desc &dc, int64_t B, int &nA, int &nC) {
   const int64_t n_tiles = (B + 15) / 16;
@@ -1757,6 +1816,20 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
     const bool wide = d.in_dim > 32;
     if (LN == 0) rc = relu ? upd16_inst<true, 0>(HEAD, wide, grid, block, lds_bytes, st, a16) : upd16_inst<false, 0>(HEAD, wide, grid, block, lds_bytes, st, a16);
     else rc = relu ? upd16_inst<true, 1>(HEAD, wide, grid, block, lds_bytes, st, a16) : upd16_inst<false, 1>(HEAD, wide, grid, block, lds_bytes, st, a16);
+  } else if ((HEAD == 1 || HEAD == 2) && upd16x_eligible(d, HEAD == 1)) {
+    // wide inputs: layer-1 forward as its own kernel (mlp_wide16.h), then the 16-sample-tile update kernel from z1 on; the
+    // caller's mappo_wide_l1_backward turns dz1 + the row statistics into the W1 / feature-norm gradients
+    MAPPO_REQUIRE(a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
+    if (int rcw = launch_wide_l1_fwd(a.params, d, a.off, a.x, a.rows, a.B, a.wide_ws + wide_z1_offset(a.B), a.wide_ws + (int64_t)HID * a.B,
+                                     a.wide_ws + (int64_t)(HID + 1) * a.B, st, who))
+      return rcw;
+    Upd16Args a16 = {};
+    a16.u = a;
+    if (int rc16 = prep16x(a16, HEAD == 1, who)) return rc16;
+    const size_t lds_bytes = upd16x_lds_floats(d, HEAD == 1) * sizeof(float);
+    dim3 grid((unsigned)nb), block(WAVE * UPD16_WAVES);
+    if (LN == 0) rc = relu ? upd16x_inst<true, 0>(HEAD, grid, block, lds_bytes, st, a16) : upd16x_inst<false, 0>(HEAD, grid, block, lds_bytes, st, a16);
+    else rc = relu ? upd16x_inst<true, 1>(HEAD, grid, block, lds_bytes, st, a16) : upd16x_inst<false, 1>(HEAD, grid, block, lds_bytes, st, a16);
   } else if (d.in_dim <= MAXD) {
     // pair kernel (mlp_upd2.h): n_pairs tiles in flight per workgroup, two waves each
     const int np = fit_waves(d, 4);
@@ -2099,7 +2172,7 @@ __global__ __launch_bounds__(256, 1) void wide_l1_bwd_kernel(WideArgs p) {
     }
 }
 
-extern "C" int64_t mappo_wide_workspace_floats(int64_t B) { return (int64_t)(HID + 2) * B; }
+extern "C" int64_t mappo_wide_workspace_floats(int64_t B) { return wide_z1_offset(B) + (int64_t)HID * B; }     // + z1 [B][64] (mlp_wide16.h)
 
 extern "C" int32_t mappo_wide_l1_slabs(int64_t B) {
   const int64_t n_tiles = (B + TS - 1) / TS, groups = (n_tiles + 3) / 4;

@@ -36,25 +36,27 @@ __device__ __forceinline__ void static_for16(F &&f) { static_for_impl16(f, std::
 
 // LDS carve-up (floats), a compile-time function of the instantiation so that every LDS address is
 // "lane pattern (one VGPR) + immediate".  W1' is staged as [f][q * CP + t] (input feature k = q * C + t, C = ceil(D / 4)).
-template <int LN, int HEAD, bool WIDE>
+template <int LN, int HEAD, bool WIDE, bool XL1 = false>
 struct L16 {
+  // XL1: layer 1 runs in its own kernels (mlp_wide16.h forward, wide_l1_bwd_kernel weight gradient): no W1 copy, no xhat0 tile
   static constexpr int CP = WIDE ? 16 : 8, RS1 = 4 * CP + 4, NBK = WIDE ? 4 : 2, XST = 16 * NBK + 4;
   static constexpr int W1 = 0;
-  static constexpr int W2 = W1 + HID * RS1;                       // W2' [f][k], row stride RS16 (layer_N == 1): forward A operand
+  static constexpr int W2 = W1 + (XL1 ? 0 : HID * RS1);                       // W2' [f][k], row stride RS16 (layer_N == 1): forward A operand
   static constexpr int W2T = W2 + (LN > 0 ? HID * RS16 : 0);      // W2'^T [k][f]: backward-data A operand (16-byte reads, too)
   static constexpr int WH = W2T + (LN > 0 ? HID * RS16 : 0);      // actor: Wh' [action][k] (16 rows, stride HS16) | critic: Wh' [k]
   static constexpr int B1 = WH + (HEAD == 1 ? 16 * HS16 : HID), B2 = B1 + HID, BH = B2 + HID;      // folded biases
   static constexpr int FN_W = BH + 16, FN_B = FN_W + HID, G1 = FN_B + HID, T1 = G1 + HID, G2 = T1 + HID, T2 = G2 + HID;   // raw affine vectors
   static constexpr int TILES = T2 + HID;
   // per-wave tiles: xhat0 [16][XST] | xhat1 [16][68] (layer_N == 1) | scratch tile [16][68] | dlogits [16][20] (actor)
-  static constexpr int UX = 0, UH = UX + 16 * XST, UT = UH + (LN > 0 ? 16 * RS16 : 0), UDL = UT + 16 * RS16;
+  static constexpr int UX = 0, UH = UX + (XL1 ? 0 : 16 * XST), UT = UH + (LN > 0 ? 16 * RS16 : 0), UDL = UT + 16 * RS16;
   static constexpr int WAVE_STRIDE = UDL + (HEAD == 1 ? 16 * DLS16 : 0);
   static constexpr int N_WAVES = UPD16_THREADS / WAVE;
-  static constexpr int TILE_AREA = N_WAVES * WAVE_STRIDE;
-  static constexpr int TOTAL = TILES + TILE_AREA;
   // epilogue (overlaid on the tile area): [1024 scratch | chunk buffer N_WAVES x CH x 256 | flat gradient (<= PMAX)]
-  static constexpr int DMAX = WIDE ? 64 : 32;
+  static constexpr int DMAX = XL1 ? 0 : (WIDE ? 64 : 32);
   static constexpr int PMAX = 2 * DMAX + HID * DMAX + 3 * HID + (LN > 0 ? HID * HID + 3 * HID : 0) + (HEAD == 1 ? 16 * HID + 16 : HID + 1);
+  static constexpr int EPI4 = 1024 + N_WAVES * 4 * 256 + PMAX;
+  static constexpr int TILE_AREA = N_WAVES * WAVE_STRIDE > EPI4 ? N_WAVES * WAVE_STRIDE : EPI4;    // small tile sets: the epilogue's need
+  static constexpr int TOTAL = TILES + TILE_AREA;
   static constexpr int CH = (1024 + N_WAVES * 8 * 256 + PMAX <= TILE_AREA) ? 8 : 4;       // accumulators per reduction chunk
   static_assert(1024 + N_WAVES * CH * 256 + PMAX <= TILE_AREA, "epilogue buffers do not fit the tile area");
 };
@@ -279,6 +281,41 @@ __device__ __forceinline__ void prefetch16(Prefetch16<WIDE> &pf, const UpdArgs &
   }
 }
 
+// XL1: the tile's input is z1 [B][64] (pre-activation of layer 1, bias included; minibatch order) from wide_l1_fwd16_kernel:
+// lane (n, q) fetches z1[16 b + 4 q .. + 3] of sample n as four bounds-checked 16-byte loads (rows beyond B read as 0).
+template <int HEAD>
+__device__ __forceinline__ void prefetch16x(Prefetch16<true> &pf, const UpdArgs &p, const float *z1, int64_t tile, int64_t n_tiles, int A,
+                                            int n, int q) {
+  const int64_t base = tile * 16;
+  const int nv = (tile < n_tiles) ? (int)min((int64_t)16, p.B - base) : 0;
+  pf.n_valid = nv;
+  pf.flat = true;
+  pf.f0 = pf.f1 = pf.f2 = pf.f3 = 0.f;
+  pf.dead = 0u;
+  if (nv == 0) return;
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void *)(z1 + base * HID), 0, nv * HID * 4, 0x00020000);
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    const f32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rz, (n * HID + 4 * q) * 4, 64 * b, 0);
+    pf.xv[4 * b + 0] = t[0]; pf.xv[4 * b + 1] = t[1]; pf.xv[4 * b + 2] = t[2]; pf.xv[4 * b + 3] = t[3];
+  }
+  const bool ok = n < nv;
+  const int64_t row = ok ? (p.rows ? (int64_t)p.rows[base + n] : base + n) : 0;
+  if constexpr (HEAD == 1) {
+    pf.f0 = p.actions[row]; pf.f1 = p.old_logp[row]; pf.f2 = p.adv[row]; pf.f3 = p.active[row];
+    if (p.avail) {
+      const float *av = p.avail + row * A;
+      float v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = av[min(4 * i + q, A - 1)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pf.dead |= ((4 * i + q < A && v[i] == 0.f) ? 1u : 0u) << i;
+    }
+  } else if constexpr (HEAD == 2) {
+    pf.f0 = p.v_old[row]; pf.f1 = p.returns[row]; pf.f2 = p.active[row];
+  }
+}
+
 // Actor objective of one sample in the head layout: lane (n, q) holds z[i] = logit of action 4 i + q (A <= 16).  On return z
 // holds d(actor objective) / d logits.  Same expressions as actor_loss_regs (mlp_core.h); the sums over actions run over
 // the lane's registers first and the 4 lanes of the sample second.
@@ -374,12 +411,15 @@ __device__ __forceinline__ void affine_epilogue16(float *R, int wo, int bo, int 
 }
 
 // Workgroup `bid` of the `nb` workgroups that share this network's rows.  512 threads (8 waves, 2 per SIMD).
-template <bool RELU, int LN, int HEAD, bool WIDE>
+template <bool RELU, int LN, int HEAD, bool WIDE, bool XL1 = false>
 __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, const int bid, const int nb) {
   static_assert(LN <= 1 && (HEAD == 1 || HEAD == 2), "update16: layer_N <= 1, in-kernel loss heads only");
+  static_assert(!XL1 || WIDE, "XL1 uses the 16-register prefetch block");
   constexpr int NV = WIDE ? 16 : 8, NBK = WIDE ? 4 : 2;
   const UpdArgs &p = P.u;
-  typedef L16<LN, HEAD, WIDE> M;
+  typedef L16<LN, HEAD, WIDE, XL1> M;
+  // XL1 workspace (mappo_wide_workspace_floats): dz1 [64][B] feature-major | mean0 [B] | rstd0 [B] | z1 [B][64]
+  const float *z1 = XL1 ? p.wide_ws + ((66 * p.B + 3) & ~(int64_t)3) : nullptr;
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), n_waves = blockDim.x / WAVE;
@@ -390,7 +430,8 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   const int64_t tile_stride = (int64_t)nb * n_waves;
   const int64_t tile0 = (int64_t)wave * nb + bid;          // remainder of the last round spreads over all CUs
   Prefetch16<WIDE> pf;
-  prefetch16<HEAD, WIDE>(pf, p, tile0, n_tiles, D, C, A, lane, n, q);
+  if constexpr (XL1) prefetch16x<HEAD>(pf, p, z1, tile0, n_tiles, A, n, q);
+  else prefetch16<HEAD, WIDE>(pf, p, tile0, n_tiles, D, C, A, lane, n, q);
   STAMP_DECL
 
   // ---- stage the network: W' = W * gamma_in (columns), b' = b + W beta_in.  Thread (f8 = tid / 8, part = tid % 8) owns the
@@ -403,10 +444,12 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     const int vid = tid >> 6, ve = tid & 63;                      // vector staging: 8 vectors x 64 entries
     float w1r[M::CP / 2], w2r[8], whr[8], vecv, b1raw, b2raw = 0.f, bhraw = 0.f;
     // W1: slot r = part + 8 j of row f8 <-> (chunk r / CP, t = r % CP) <-> input feature k = chunk * C + t
+    if constexpr (!XL1) {
 #pragma unroll
-    for (int j = 0; j < M::CP / 2; ++j) {
-      const int r = part + 8 * j, k = (r / M::CP) * C + (r % M::CP);
-      w1r[j] = g[o.w1 + f8 * D + min(k, D - 1)];
+      for (int j = 0; j < M::CP / 2; ++j) {
+        const int r = part + 8 * j, k = (r / M::CP) * C + (r % M::CP);
+        w1r[j] = g[o.w1 + f8 * D + min(k, D - 1)];
+      }
     }
     if constexpr (LN > 0) {
 #pragma unroll
@@ -425,8 +468,8 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     {
       // vectors: 0 fn_w | 1 fn_b | 2 g1 | 3 t1 | 4 g2 | 5 t2 (6, 7 idle)
       int src = -1; float fill = 0.f;
-      if (vid == 0) { if (fnorm) { if (ve < D) src = o.fn_w + ve; } else fill = 1.f; }
-      else if (vid == 1) { if (fnorm && ve < D) src = o.fn_b + ve; }
+      if (vid == 0) { if (fnorm && !XL1) { if (ve < D) src = o.fn_w + ve; } else fill = 1.f; }
+      else if (vid == 1) { if (fnorm && !XL1 && ve < D) src = o.fn_b + ve; }
       else if (vid == 2) src = o.ln1_w + ve;
       else if (vid == 3) src = o.ln1_b + ve;
       else if (vid == 4) { if (LN > 0) src = o.ln2_w[0] + ve; }
@@ -435,7 +478,7 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       vecv = src >= 0 ? ld : fill;
     }
     // zero-fill this wave's xhat0 tile (its padding columns feed gradient columns that are never stored)
-    {
+    if constexpr (!XL1) {
       float *Ux0 = lds + M::TILES + wave * M::WAVE_STRIDE + M::UX;
       for (int e = lane; e < 16 * M::XST / 4; e += WAVE) *reinterpret_cast<float4 *>(Ux0 + 4 * e) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
@@ -443,14 +486,16 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     __syncthreads();
     const int gl = LN > 0 ? M::G2 : M::G1, tl = LN > 0 ? M::T2 : M::T1;       // LayerNorm feeding the head
     float pb1 = 0.f, pb2 = 0.f, pbh = 0.f;
+    if constexpr (!XL1) {
 #pragma unroll
-    for (int j = 0; j < M::CP / 2; ++j) {
-      const int r = part + 8 * j, t = r % M::CP, k = (r / M::CP) * C + t;
-      const bool ok = t < C && k < D;                            // padding slots of the staged copy are zero
-      const int kc = min(k, 63);
-      const float w = ok ? w1r[j] : 0.f;
-      lds[M::W1 + f8 * M::RS1 + r] = w * lds[M::FN_W + kc];
-      pb1 += w * lds[M::FN_B + kc];
+      for (int j = 0; j < M::CP / 2; ++j) {
+        const int r = part + 8 * j, t = r % M::CP, k = (r / M::CP) * C + t;
+        const bool ok = t < C && k < D;                          // padding slots of the staged copy are zero
+        const int kc = min(k, 63);
+        const float w = ok ? w1r[j] : 0.f;
+        lds[M::W1 + f8 * M::RS1 + r] = w * lds[M::FN_W + kc];
+        pb1 += w * lds[M::FN_B + kc];
+      }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -506,7 +551,8 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   float lacc[3] = {0.f, 0.f, 0.f};
 
   // ---- raw-product accumulators of this wave ----
-  f32x4 gW1[4][NBK], gW2[LN > 0 ? 4 : 1][LN > 0 ? 4 : 1], gWh[1][HEAD == 1 ? 4 : 1];
+  f32x4 gW1[XL1 ? 1 : 4][XL1 ? 1 : NBK], gW2[LN > 0 ? 4 : 1][LN > 0 ? 4 : 1], gWh[1][HEAD == 1 ? 4 : 1];
+  f32x4 gB1x[XL1 ? 4 : 1];                                      // XL1: per-lane sums of dz1 (feature 16 b + 4 q + i of the lane's samples)
   // bias-gradient partials: gB1/gB2[bf] = sum over this lane's samples of dz[16 bf + n] (reduced over q in the epilogue);
   // gBh: actor = the same for d logits (action n), critic = per-lane sum of dv; gWc: critic raw head product, lane = k
   float gB1[4] = {0.f, 0.f, 0.f, 0.f}, gB2[4] = {0.f, 0.f, 0.f, 0.f}, gBh[1] = {0.f}, gWc = 0.f;
@@ -514,8 +560,12 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
     for (int bf = 0; bf < 4; ++bf) {
+      if constexpr (!XL1) {
 #pragma unroll
-      for (int bk = 0; bk < NBK; ++bk) gW1[bf][bk][i] = 0.f;
+        for (int bk = 0; bk < NBK; ++bk) gW1[bf][bk][i] = 0.f;
+      } else {
+        gB1x[bf][i] = 0.f;
+      }
       if constexpr (LN > 0) {
 #pragma unroll
         for (int bk = 0; bk < 4; ++bk) gW2[bf][bk][i] = 0.f;
@@ -535,6 +585,15 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     const bool live = n < n_valid;
     const float c0 = pf.f0, c1 = pf.f1, c2 = pf.f2, c3 = pf.f3;
     const uint32_t cdead = pf.dead;
+    f32x4 xh[4];
+    float mean1, rstd1, mean2 = 0.f, rstd2 = 1.f;
+    uint32_t pos1, pos2 = 0u;
+    if constexpr (XL1) {
+      // layer 1 ran in wide_l1_fwd16_kernel: the prefetched registers ARE the pre-activations (bias included)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { xh[b][0] = pf.xv[4 * b]; xh[b][1] = pf.xv[4 * b + 1]; xh[b][2] = pf.xv[4 * b + 2]; xh[b][3] = pf.xv[4 * b + 3]; }
+      STAMP(1);
+    } else {
     // ---- xhat0: LayerNorm over the D input features (mlp.py:45,51-52); lane holds k = q C + t ----
     float x0[NV];
     {
@@ -576,9 +635,6 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
 
     STAMP(1);   // xhat0
     // ---- layer 1 ----
-    f32x4 xh[4];
-    float mean1, rstd1, mean2 = 0.f, rstd2 = 1.f;
-    uint32_t pos1, pos2 = 0u;
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo) xh[bo] = ld4(lds + M::B1 + 16 * bo + 4 * q);
 #pragma unroll
@@ -596,10 +652,12 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
         }
       }
     }
+    }
     STAMP(2);   // layer 1 MFMA
     // next tile, under this tile's MFMAs (issued after the loss instead, the prefetch registers live through the
     // register-hungry backward pass only — but that is where the pressure peaks: 106 spilled registers, measured)
-    prefetch16<HEAD, WIDE>(pf, p, tile + tile_stride, n_tiles, D, C, A, lane, n, q);
+    if constexpr (XL1) prefetch16x<HEAD>(pf, p, z1, tile + tile_stride, n_tiles, A, n, q);
+    else prefetch16<HEAD, WIDE>(pf, p, tile + tile_stride, n_tiles, D, C, A, lane, n, q);
     act_ln_fwd16<RELU>(xh, mean1, rstd1, pos1);
     STAMP(3);   // prefetch issue + act/LN 1
     // ---- hidden layer ----
@@ -698,12 +756,27 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     }
     STAMP(9);   // d xhat1
     ln_act_bwd16<RELU>(dx, xh, mean1, rstd1, pos1);            // dx = dz1
+    if constexpr (XL1) {
+      // dz1 goes to HBM feature-major for wide_l1_bwd_kernel (W1 / feature-norm gradients: 64 x in_dim accumulators do not
+      // fit a wave); the bias gradient accumulates per lane
+      float *dz1T = p.wide_ws;
+      const int64_t col = tile * 16 + n;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, dx[b]);
-    wave_lds_sync();
-    STAMP(10);  // LN1 backward + tile write
-    dw_accum16<4, NBK>(gW1, gB1, Ut, RS16, Ux, xs, n, q);
-    wave_lds_sync();
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (live) dz1T[(int64_t)(16 * b + 4 * q + i) * p.B + col] = dx[b][i];
+          gB1x[b][i] += dx[b][i];
+        }
+      STAMP(10);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, dx[b]);
+      wave_lds_sync();
+      STAMP(10);  // LN1 backward + tile write
+      dw_accum16<4, NBK>(gW1, gB1, Ut, RS16, Ux, xs, n, q);
+      wave_lds_sync();
+    }
     STAMP(11);  // dW1
   }
 
@@ -720,7 +793,15 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       for (int j = 0; j < 8; ++j) ew2[j] = p.params[o.w2[0] + (part + 8 * j) * HID + k];
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ew1[j] = fnorm ? p.params[o.w1 + (part + 8 * j) * D + min(k, D - 1)] : 0.f;
+    for (int j = 0; j < 8; ++j) ew1[j] = (fnorm && !XL1) ? p.params[o.w1 + (part + 8 * j) * D + min(k, D - 1)] : 0.f;
+  }
+  float gB1x_f = 0.f;
+  if constexpr (XL1) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, gB1x[b]);
+    wave_lds_sync();
+    gB1x_f = col_sum16(Ut, RS16, lane);                         // lane = feature
+    wave_lds_sync();
   }
   __syncthreads();                                              // every wave is done with its tiles: the tile area is free
   STAMP(13);  // transform loads + first barrier (slowest wave of the workgroup)
@@ -736,7 +817,7 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     float t1[4], t2[4];
 #pragma unroll
     for (int bf = 0; bf < 4; ++bf) { t1[bf] = quad_sum16(gB1[bf]); t2[bf] = LN > 0 ? quad_sum16(gB2[bf]) : 0.f; }
-    gB1f = q == 0 ? t1[0] : (q == 1 ? t1[1] : (q == 2 ? t1[2] : t1[3]));
+    gB1f = XL1 ? gB1x_f : (q == 0 ? t1[0] : (q == 1 ? t1[1] : (q == 2 ? t1[2] : t1[3])));
     gB2f = q == 0 ? t2[0] : (q == 1 ? t2[1] : (q == 2 ? t2[2] : t2[3]));
     gBhf = HEAD == 1 ? quad_sum16(gBh[0]) : wave_sum_f(gBh[0]);   // actor: lane n < 16 = action | critic: sum of dv in lane 0
   }
@@ -751,8 +832,9 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   const int Pn = o.total;
   constexpr int CH = M::CH;                                     // accumulators per chunk (8 | 4)
   float *cb = scr + 1024;                                       // chunk buffer: n_waves x CH x 256 floats
-  float *R0 = cb + M::N_WAVES * CH * 256;
-  constexpr int N1 = 4 * NBK, N2 = LN > 0 ? 16 : 0, NH = HEAD == 1 ? 4 : 0, NACC = N1 + N2 + NH;
+  const int rb = XL1 ? o.b1 : 0;                                // XL1: W1 / feature-norm gradients are not this kernel's
+  float *R0 = cb + M::N_WAVES * CH * 256 - rb;                  // indexed by absolute flat offsets >= rb
+  constexpr int N1 = XL1 ? 0 : 4 * NBK, N2 = LN > 0 ? 16 : 0, NH = HEAD == 1 ? 4 : 0, NACC = N1 + N2 + NH;
   auto acc_of = [&](auto idc) -> f32x4 & {
     constexpr int id = decltype(idc)::value;
     if constexpr (id < N1) return gW1[id / NBK][id % NBK];
@@ -824,11 +906,11 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     const int ogl = LN > 0 ? o.ln2_w[0] : o.ln1_w, otl = LN > 0 ? o.ln2_b[0] : o.ln1_b;
     affine_epilogue16<NJH>(R0, o.wh, o.bh, A, HID, lds + gl, lds + tl, ewh, ogl, otl, scr);
     if constexpr (LN > 0) affine_epilogue16<8>(R0, o.w2[0], o.b2[0], HID, HID, lds + M::G1, lds + M::T1, ew2, o.ln1_w, o.ln1_b, scr);
-    if (fnorm) affine_epilogue16<8>(R0, o.w1, o.b1, HID, D, lds + M::FN_W, lds + M::FN_B, ew1, o.fn_w, o.fn_b, scr);
+    if (fnorm && !XL1) affine_epilogue16<8>(R0, o.w1, o.b1, HID, D, lds + M::FN_W, lds + M::FN_B, ew1, o.fn_w, o.fn_b, scr);
   }
   STAMP(15);  // raw -> gradient transform
   float *slab = p.slabs + (size_t)bid * p.slab_stride + p.slab_col0;
-  for (int e = threadIdx.x; e < Pn; e += blockDim.x) slab[e] = R0[e];
+  for (int e = rb + threadIdx.x; e < Pn; e += blockDim.x) slab[e] = R0[e];
   if (threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -851,6 +933,13 @@ template <bool RELU, int LN, int HEAD, bool WIDE>
 __global__ __launch_bounds__(512, 2) void mlp_update16_kernel(Upd16Args a) {
   extern __shared__ __align__(16) float lds[];
   update16_body<RELU, LN, HEAD, WIDE>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// Wide inputs (in_dim 65..512): the network from z1 on; layer 1 forward = wide_l1_fwd16_kernel, its weight gradient = wide_l1_bwd_kernel
+template <bool RELU, int LN, int HEAD>
+__global__ __launch_bounds__(512, 2) void mlp_update16x_kernel(Upd16Args a) {
+  extern __shared__ __align__(16) float lds[];
+  update16_body<RELU, LN, HEAD, true, true>(a, lds, blockIdx.x, gridDim.x);
 }
 
 // Actor AND critic in one launch: workgroups [0, nA) the actor's update, [nA, nA + nC) the critic's; the shares follow the

@@ -1,0 +1,169 @@
+// mlp_wide16.h — layer 1 of the MLP trunk for wide inputs (in_dim 65..512: SMAC 25m observations / states, the 512-wide
+// stress config), as its own kernel on v_mfma_f32_16x16x4_f32:
+//     z1[s][f] = b1'[f] + sum_k W1'[f][k] xhat0[s][k],   xhat0 = LayerNorm(x[s]) without affine (folded: W1' = W1 gamma0, b1' = b1 + W1 beta0)
+// (mlp.py:45,51-55: feature norm + fc1 up to the pre-activation) plus the row statistics (mean0, rstd0) the weight-gradient
+// kernel needs.  The rest of the network runs from z1 (mlp_upd16.h with XL1, 64 values per sample instead of in_dim).
+//
+// Why a separate kernel: with in_dim = 512 layer 1 is 88 % of the forward MACs but W1 (128 KB) does not fit LDS next to
+// anything else and its gradient (64 x 512 accumulators) does not fit a wave.  Round 1 K-chunked it inside the one-wave-per-
+// tile update kernel: 7 % of the fp32 MFMA peak (profiles/r02/c_configs345_kernel_stats_before_wide16.txt).  Here:
+//   * a wave owns a 16-sample tile and keeps its WHOLE input row block in registers (16 NCH values per lane: lane (n, q)
+//     holds columns 64 c + 16 q + j of sample n), read ONCE from HBM as 16-byte loads; the LayerNorm statistics are the exact
+//     two-pass form on those registers; the registers are the B operands as they are (k-step (c, j) <-> column 64 c + 16 q + j);
+//   * the 8 waves of a workgroup share each 64-column chunk of W1' through a double-buffered LDS tile [64][68]: chunk c + 1 is
+//     fetched (global -> registers) under the 64 MFMAs of chunk c and stored before the single barrier per chunk;
+//   * output z1 [B][64] row-major (the accumulator layout gives each lane 4 x 16 contiguous bytes).
+#pragma once
+
+struct Wide16Args {
+  const float *params, *x;
+  const int32_t *rows;
+  float *z1;                 // [B][64]
+  float *mean0, *rstd0;      // [B] each (may be NULL: rollout forward)
+  int64_t B;
+  int D, w1, b1, fn_w, fn_b; // offsets into params (fn_* < 0: no feature norm)
+};
+
+// b1'[f] = b1[f] + sum_k W1[f][k] beta0[k]   (64 rows x 8 threads, all 512 threads)
+__device__ __forceinline__ void wide16_fold_bias(const Wide16Args &p, float *sB) {
+  const int tid = threadIdx.x, f = tid >> 3, part = tid & 7;
+  float acc = 0.f;
+  if (p.fn_b >= 0) {
+    const float *w = p.params + p.w1 + (size_t)f * p.D, *bt = p.params + p.fn_b;
+    for (int k0 = part; k0 < p.D; k0 += 64) {
+      float wv[8], bv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const int k = min(k0 + 8 * j, p.D - 1); wv[j] = w[k]; bv[j] = bt[k]; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) if (k0 + 8 * j < p.D) acc += wv[j] * bv[j];
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) acc += __shfl_xor(acc, off, WAVE);
+  if (part == 0) sB[f] = p.params[p.b1 + f] + acc;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
+  __shared__ __align__(16) float sW[2][HID * RS16];       // W1' chunk [f][k], double buffered
+  __shared__ __align__(16) float sB[HID];
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = p.D;
+  const bool fnorm = p.fn_w >= 0;
+  const bool al4 = (D & 3) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)(p.params + p.w1))) & 15) == 0;
+  const float inv_D = 1.0f / (float)D;
+  wide16_fold_bias(p, sB);
+
+  // this thread's share of a weight chunk: row wf, columns 8 wp .. 8 wp + 7 (64 rows x 8 threads)
+  const int wf = tid >> 3, wp = tid & 7;
+  auto fetch_chunk = [&](int c, float (&w)[8]) {
+    const int k0 = 64 * c + 8 * wp;
+    const float *src = p.params + p.w1 + (size_t)wf * D + k0;
+    if (al4 && k0 + 8 <= D) {
+      const float4 a = reinterpret_cast<const float4 *>(src)[0], b = reinterpret_cast<const float4 *>(src)[1];
+      w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (k0 + j < D) ? src[min(j, D - 1 - min(k0, D - 1))] : 0.f;
+    }
+    if (fnorm) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (k0 + j < D) ? w[j] * p.params[p.fn_w + min(k0 + j, D - 1)] : 0.f;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = (k0 + j < D) ? w[j] : 0.f;
+    }
+  };
+  auto store_chunk = [&](int buf, const float (&w)[8]) {
+    float *dst = &sW[buf][wf * RS16 + 8 * wp];
+    *reinterpret_cast<float4 *>(dst) = make_float4(w[0], w[1], w[2], w[3]);
+    *reinterpret_cast<float4 *>(dst + 4) = make_float4(w[4], w[5], w[6], w[7]);
+  };
+
+  const int64_t n_tiles = (p.B + 15) / 16;
+  const int64_t n_groups = (n_tiles + 7) / 8;                 // 8 tiles (one per wave) share the weight stream
+  const int n_chunks = (D + 63) / 64;
+  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
+    const int64_t tile = grp * 8 + wave;
+    const int64_t i = tile * 16 + n;
+    const bool ok = i < p.B;
+    const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
+    const float *xr = p.x + row * D;
+    // ---- the row block into registers: column 64 c + 16 q + j ----
+    float xv[NCH][16];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int k0 = 64 * c + 16 * q;
+      if (al4 && k0 + 16 <= D) {
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) {
+          const float4 t = reinterpret_cast<const float4 *>(xr + k0)[j4];
+          xv[c][4 * j4] = t.x; xv[c][4 * j4 + 1] = t.y; xv[c][4 * j4 + 2] = t.z; xv[c][4 * j4 + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv[c][j] = xr[min(k0 + j, D - 1)];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv[c][j] = (k0 + j < D) ? xv[c][j] : 0.f;
+      }
+    }
+    float w_next[8];
+    fetch_chunk(0, w_next);
+    // ---- LayerNorm statistics over the D inputs (exact two-pass on the registers) ----
+    float mean = 0.f, rstd = 1.f;
+    if (fnorm) {
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s4[j & 3] += xv[c][j];
+      mean = quad_sum16((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_D;
+      float v4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float d = (64 * c + 16 * q + j < D) ? xv[c][j] - mean : 0.f;
+          xv[c][j] = d;
+          v4[j & 3] += d * d;
+        }
+      rstd = 1.0f / sqrtf(quad_sum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * inv_D + LN_EPS);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) xv[c][j] *= rstd;
+    }
+    if (ok && q == 0 && p.mean0) { p.mean0[i] = mean; p.rstd0[i] = rstd; }
+    // ---- z1 = b1' + W1' xhat0, chunk by chunk ----
+    __syncthreads();                                           // sB ready (first group) / previous group's last chunk consumed
+    store_chunk(0, w_next);
+    f32x4 acc[4];
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) acc[bo] = ld4(sB + 16 * bo + 4 * q);
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c < n_chunks) {
+        if (c + 1 < n_chunks) fetch_chunk(c + 1, w_next);
+        const float *Wc = &sW[c & 1][n * RS16 + 16 * q];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          f32x4 a[4];
+#pragma unroll
+          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + 16 * bo * RS16 + 4 * jj);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) acc[bo] = mfma16(a[bo][t], xv[c][4 * jj + t], acc[bo]);
+        }
+        if (c + 1 < n_chunks) store_chunk((c + 1) & 1, w_next);
+        __syncthreads();
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) st4(p.z1 + i * HID + 16 * b + 4 * q, acc[b]);
+    }
+  }
+}
