@@ -2175,8 +2175,8 @@ __global__ __launch_bounds__(256, 1) void wide_l1_bwd_kernel(WideArgs p) {
 extern "C" int64_t mappo_wide_workspace_floats(int64_t B) { return wide_z1_offset(B) + (int64_t)HID * B; }     // + z1 [B][64] (mlp_wide16.h)
 
 extern "C" int32_t mappo_wide_l1_slabs(int64_t B) {
-  const int64_t n_tiles = (B + TS - 1) / TS, groups = (n_tiles + 3) / 4;
-  return (int32_t)(groups < 32 ? groups : 32);
+  // slab rows mappo_wide_l1_backward may write (never more than the update launch's own mappo_mlp_backward_slabs(B))
+  return mappo_mlp_backward_slabs(B);
 }
 
 extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
@@ -2185,6 +2185,26 @@ extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc 
   if (int rc = check_desc_trunk(desc, "wide_l1_backward")) return rc;
   MAPPO_REQUIRE(desc->in_dim > MAXD, "wide_l1_backward: in_dim %d is handled inside the update kernels", desc->in_dim);
   MAPPO_REQUIRE(params && x && wide_ws && slabs && B > 0, "wide_l1_backward: bad arguments");
+  {
+    const char *e16 = getenv("MAPPO_UPD16");
+    if (!(e16 && e16[0] == '0') && desc->in_dim <= 512) {
+      // 16x16x4 kernel (mlp_wide16.h): raw products, every input element read once
+      const NetOff o = net_offsets(*desc);
+      MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + o.total <= slab_stride, "wide_l1_backward: slab column range");
+      WideBwd16Args w = {};
+      w.params = params; w.x = x; w.rows = rows; w.wide_ws = wide_ws; w.slabs = slabs; w.slab_stride = slab_stride; w.slab_col0 = slab_col0;
+      w.B = B; w.D = desc->in_dim; w.w1 = o.w1; w.fn_w = desc->use_feature_norm ? o.fn_w : -1; w.fn_b = desc->use_feature_norm ? o.fn_b : -1;
+      const int nch = (desc->in_dim + 63) / 64;
+      w.nca = nch <= 2 ? 2 : (nch <= 4 ? 4 : 8);
+      const int rows_max = mappo_mlp_backward_slabs(B);
+      w.groups = 8 / w.nca;
+      if (rows_max < w.groups) w.groups = 1;
+      const int gx = rows_max / w.groups;
+      hipLaunchKernelGGL(wide_l1_bwd16_kernel<0>, dim3((unsigned)gx), dim3(512), 0, as_stream(stream), w);
+      MAPPO_CHECK_LAUNCH("wide_l1_backward");
+      return MAPPO_OK;
+    }
+  }
   MAPPO_CLEAR_STICKY();
   WideArgs a = {};
   a.params = params; a.x = x; a.rows = rows; a.wide_ws = wide_ws; a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;

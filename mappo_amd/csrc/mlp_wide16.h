@@ -59,13 +59,13 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   const int wf = tid >> 3, wp = tid & 7;
   auto fetch_chunk = [&](int c, float (&w)[8]) {
     const int k0 = 64 * c + 8 * wp;
-    const float *src = p.params + p.w1 + (size_t)wf * D + k0;
+    const float *wrow = p.params + p.w1 + (size_t)wf * D, *src = wrow + k0;
     if (al4 && k0 + 8 <= D) {
       const float4 a = reinterpret_cast<const float4 *>(src)[0], b = reinterpret_cast<const float4 *>(src)[1];
       w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = (k0 + j < D) ? src[min(j, D - 1 - min(k0, D - 1))] : 0.f;
+      for (int j = 0; j < 8; ++j) w[j] = wrow[min(k0 + j, D - 1)];          // masked below
     }
     if (fnorm) {
 #pragma unroll
@@ -164,6 +164,146 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
     if (ok) {
 #pragma unroll
       for (int b = 0; b < 4; ++b) st4(p.z1 + i * HID + 16 * b + 4 * q, acc[b]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
+// wide_l1_bwd16_kernel — weight gradient of layer 1 and the feature-norm gradients for in_dim 65..512 from dz1 (feature-major
+// [64][B]) and the row statistics the forward left:
+//     G[f][k] = sum_s dz1[f][s] xhat0[k][s]   (RAW product: xhat0 without the affine),   db[f] = sum_s dz1[f][s]
+//     dW1 = gamma0[k] G + beta0[k] db[f],   dgamma0[k] = sum_f W1[f][k] G[f][k],   dbeta0[k] = sum_f W1[f][k] db[f]
+// (the raw-product identities of mlp_impl.h: no dX = W1^T dz1 pass — half the MFMA work of the round-1 kernel, which also
+// re-read dz1 once per 64-column chunk).  A workgroup walks 16-sample tiles; wave w owns the 64-column chunk w % NCA of W1's
+// gradient (64 accumulator registers) for the tiles of its tile group w / NCA:
+//   * A operand = dz1^T: lane (m, q) needs dz1[16 bf + m][4 q .. 4 q + 3] — ONE 16-byte load from the feature-major array;
+//   * B operand = xhat0^T of the chunk: lane (n, q) reads x[row 4 q + j][chunk + 16 bk + n] (64-byte segments; every input
+//     element is read exactly once by exactly one wave) and normalises it with the sample's (mean0, rstd0);
+//   * 64 MFMAs per tile and wave; the next tile's operands are fetched under them.
+// The transform above runs per wave in registers at the end (it is linear, so it commutes with the slab reduction); one slab
+// row per (workgroup, tile group).
+// ------------------------------------------------------------------------------------------------------------------------
+struct WideBwd16Args {
+  const float *params, *x;
+  const int32_t *rows;
+  const float *wide_ws;      // dz1 [64][B] | mean0 [B] | rstd0 [B]
+  float *slabs;
+  int64_t slab_stride, slab_col0, B;
+  int D, w1, fn_w, fn_b;     // fn_* < 0: no feature norm
+  int nca, groups;           // chunk owners per tile group (power of two >= number of chunks), tile groups (nca * groups <= 8)
+};
+
+struct WideBwdOps {
+  f32x4 a[4];                // dz1[16 bf + m][4 q + j]
+  float b[4][4];             // x[row 4 q + j][chunk + 16 bk + n]  (b[j][bk])
+  f32x4 mean, rstd;          // of samples 4 q + j
+};
+
+__device__ __forceinline__ void wide_bwd_fetch(WideBwdOps &o, const WideBwd16Args &p, int64_t tile, int c0, int n, int q, bool al) {
+  const int64_t base = tile * 16, s0 = base + 4 * q;
+  const float *dz = p.wide_ws, *st = p.wide_ws + (int64_t)HID * p.B;
+  const bool full = base + 16 <= p.B;
+  if (full && al) {
+#pragma unroll
+    for (int bf = 0; bf < 4; ++bf) o.a[bf] = ld4(dz + (int64_t)(16 * bf + n) * p.B + s0);
+    o.mean = ld4(st + s0);
+    o.rstd = ld4(st + p.B + s0);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t s = min(s0 + j, p.B - 1);
+      const bool ok = s0 + j < p.B;
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf) { const float v = dz[(int64_t)(16 * bf + n) * p.B + s]; o.a[bf][j] = ok ? v : 0.f; }
+      o.mean[j] = st[s]; o.rstd[j] = st[p.B + s];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t s = min(s0 + j, p.B - 1);
+    const int64_t row = p.rows ? (int64_t)p.rows[s] : s;
+    const float *xr = p.x + row * p.D;
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) o.b[j][bk] = xr[min(c0 + 16 * bk + n, p.D - 1)];
+  }
+}
+
+template <int UNUSED>            // (a template only so that the header may be included by every translation unit)
+__global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) {
+  __shared__ float sDb[8][HID];
+  const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int chunk = wave % p.nca, tg = wave / p.nca;
+  const int c0 = 64 * chunk;
+  const bool active = tg < p.groups && c0 < p.D;
+  const bool fnorm = p.fn_w >= 0;
+  const bool al = (p.B & 3) == 0 && (((uintptr_t)p.wide_ws) & 15) == 0;
+  f32x4 G[4][4];
+  float db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int bf = 0; bf < 4; ++bf)
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) { G[bf][bk][0] = 0.f; G[bf][bk][1] = 0.f; G[bf][bk][2] = 0.f; G[bf][bk][3] = 0.f; }
+  const int64_t n_tiles = (p.B + 15) / 16;
+  const int64_t stride = (int64_t)gridDim.x * p.groups;
+  if (active) {
+    int64_t tile = (int64_t)blockIdx.x * p.groups + tg;
+    WideBwdOps cur, nxt;
+    if (tile < n_tiles) wide_bwd_fetch(cur, p, tile, c0, n, q, al);
+    for (; tile < n_tiles; tile += stride) {
+      if (tile + stride < n_tiles) wide_bwd_fetch(nxt, p, tile + stride, c0, n, q, al);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float b[4];
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk) {
+          const float raw = (c0 + 16 * bk + n < p.D) ? cur.b[j][bk] : 0.f;
+          b[bk] = fnorm ? ((c0 + 16 * bk + n < p.D) ? (raw - cur.mean[j]) * cur.rstd[j] : 0.f) : raw;
+        }
+#pragma unroll
+        for (int bf = 0; bf < 4; ++bf) {
+          db[bf] += cur.a[bf][j];
+#pragma unroll
+          for (int bk = 0; bk < 4; ++bk) G[bf][bk] = mfma16(cur.a[bf][j], b[bk], G[bf][bk]);
+        }
+      }
+      cur = nxt;
+    }
+  }
+  // ---- raw products -> gradients, per wave (db: lane (m, q) holds the sum over its samples of dz1[16 bf + m]) ----
+#pragma unroll
+  for (int bf = 0; bf < 4; ++bf) db[bf] = quad_sum16(db[bf]);
+  if (q == 0) {
+#pragma unroll
+    for (int bf = 0; bf < 4; ++bf) sDb[wave][16 * bf + n] = db[bf];
+  }
+  wave_lds_sync();
+  if (!active) return;
+  float *slab = p.slabs + (size_t)((int64_t)blockIdx.x * p.groups + tg) * p.slab_stride + p.slab_col0;
+  float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int bk = 0; bk < 4; ++bk) {
+    const int k = c0 + 16 * bk + n;
+    const bool kv = k < p.D;
+    const int kc = kv ? k : p.D - 1;
+    const float gam = fnorm ? p.params[p.fn_w + kc] : 1.f, bet = fnorm ? p.params[p.fn_b + kc] : 0.f;
+#pragma unroll
+    for (int bf = 0; bf < 4; ++bf) {
+      const f32x4 dbv = ld4(&sDb[wave][16 * bf + 4 * q]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = 16 * bf + 4 * q + i;
+        const float g = G[bf][bk][i];
+        if (fnorm) {
+          const float w = p.params[p.w1 + f * p.D + kc];
+          dgam[bk] += w * g; dbet[bk] += w * dbv[i];
+        }
+        if (kv) slab[p.w1 + f * p.D + k] = gam * g + bet * dbv[i];
+      }
+    }
+    if (fnorm) {
+      const float dg = quad_sum16(dgam[bk]), dt = quad_sum16(dbet[bk]);
+      if (q == 0 && kv) { slab[p.fn_w + k] = dg; slab[p.fn_b + k] = dt; }
     }
   }
 }
