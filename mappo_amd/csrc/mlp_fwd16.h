@@ -63,6 +63,68 @@ __device__ __forceinline__ void layer16(f32x4 (&out)[NB], const f32x4 (&h)[4], c
     }
 }
 
+// Everything after layer 1's pre-activation h (bias included): act + LayerNorm, hidden layers, head / sampling / trunk output.
+template <bool RELU, int LN, int MODE>
+__device__ __forceinline__ void forward16_tail(const FwdArgs &p, float *lds, const LdsMap &m, f32x4 (&h)[4], const int64_t i, const bool ok,
+                                               const int j, const int q, float *tZ) {
+  const int A = p.desc.out_dim;
+  act_ln16<RELU>(h, lds + m.ln1_w, lds + m.ln1_b, q);
+#pragma unroll
+  for (int l = 0; l < LN; ++l) {
+    f32x4 h2[4];
+    layer16<4>(h2, h, lds + m.w2[l], WP, lds + m.b2[l], j, q);
+    act_ln16<RELU>(h2, lds + m.ln2_w[l], lds + m.ln2_b[l], q);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) h[b] = h2[b];
+  }
+  // ---- head ----
+  if (MODE == 2) {
+    if (ok) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.out[(int64_t)(16 * b + 4 * q + r) * p.B + i] = h[b][r];      // 16 samples x 4 B per segment
+    }
+  } else if (MODE == 0) {
+    if (A == 1) {
+      f32x4 z[1];
+      layer16<1>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
+      if (ok && q == 0) p.out[i] = z[0][0];                                    // out_dim 1: row a = 0 sits in (q = 0, r = 0)
+    } else {                                                                   // logits [B][A] (mlp_forward on an actor)
+      f32x4 z[2];
+      layer16<2>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
+      if (ok) {
+#pragma unroll
+        for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int a = 16 * bo + 4 * q + r;
+            if (a < A) p.out[i * A + a] = z[bo][r];
+          }
+      }
+    }
+  } else {
+    f32x4 z[2];
+    layer16<2>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
+#pragma unroll
+    for (int bo = 0; bo < 2; ++bo)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int a = 16 * bo + 4 * q + r;
+        if (a < A) tZ[j * TP + a] = z[bo][r];
+      }
+    wave_lds_sync();
+    if (ok && q == 0) {
+      const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+      float action, logp;
+      categorical_act_lane(tZ + j * TP, A, p.avail ? p.avail + i * A : nullptr, p.deterministic != 0, p.seed, ctr, (uint64_t)i, action, logp);
+      p.actions[i] = action;
+      p.logp[i] = logp;
+    }
+    wave_lds_sync();
+  }
+}
+
 // workgroup `bid` of `nb`; MODE 0: out[i] = value (critic, out_dim 1) | MODE 1: sample / argmax + log-prob (actor)
 // | MODE 2: the trunk's output (LayerNorm of the last hidden layer) feature-major, out[64][B] (recurrent networks)
 template <bool RELU, int LN, int MODE>
@@ -131,46 +193,6 @@ __device__ __forceinline__ void forward16_body(const FwdArgs &p, float *lds, con
         }
       }
     }
-    act_ln16<RELU>(h, lds + m.ln1_w, lds + m.ln1_b, q);
-#pragma unroll
-    for (int l = 0; l < LN; ++l) {
-      f32x4 h2[4];
-      layer16<4>(h2, h, lds + m.w2[l], WP, lds + m.b2[l], j, q);
-      act_ln16<RELU>(h2, lds + m.ln2_w[l], lds + m.ln2_b[l], q);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) h[b] = h2[b];
-    }
-    // ---- head ----
-    if (MODE == 2) {
-      if (ok) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) p.out[(int64_t)(16 * b + 4 * q + r) * p.B + i] = h[b][r];      // 16 samples x 4 B per segment
-      }
-    } else if (MODE == 0) {
-      f32x4 z[1];
-      layer16<1>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
-      if (ok && q == 0) p.out[i] = z[0][0];                                      // out_dim 1: row a = 0 sits in (q = 0, r = 0)
-    } else {
-      f32x4 z[2];
-      layer16<2>(z, h, lds + m.wh, HP, lds + m.bh, j, q);
-#pragma unroll
-      for (int bo = 0; bo < 2; ++bo)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int a = 16 * bo + 4 * q + r;
-          if (a < A) tZ[j * TP + a] = z[bo][r];
-        }
-      wave_lds_sync();
-      if (ok && q == 0) {
-        const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
-        float action, logp;
-        categorical_act_lane(tZ + j * TP, A, p.avail ? p.avail + i * A : nullptr, p.deterministic != 0, p.seed, ctr, (uint64_t)i, action, logp);
-        p.actions[i] = action;
-        p.logp[i] = logp;
-      }
-      wave_lds_sync();
-    }
+    forward16_tail<RELU, LN, MODE>(p, lds, m, h, i, ok, j, q, tZ);
   }
 }

@@ -1643,6 +1643,37 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
   int64_t nb = (n_tiles + nw - 1) / nw;
   if (nb > NUM_CU) nb = NUM_CU;
   dim3 grid((unsigned)nb), block(WAVE * nw);
+  {
+    const char *e16 = getenv("MAPPO_UPD16");
+    if (a.desc.in_dim > MAXD && a.desc.in_dim <= 512 && a.x_M == 0 && !(e16 && e16[0] == '0')) {
+      // wide inputs: layer 1 from registers + double-buffered W1 chunks, the rest of the network on the same tile (mlp_wide16.h)
+      a.map.wave_stride = 16 * TP;                               // the tail only needs the [16][TP] logits tile of a wave
+      a.map.total = a.map.tiles + 8 * a.map.wave_stride;
+      const size_t lb = (size_t)a.map.total * sizeof(float);
+      MAPPO_REQUIRE(lb + sizeof(float) * (2 * HID * RS16 + HID) <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lb);
+      Wide16Args w = {};
+      w.params = a.params; w.x = a.x; w.rows = a.rows; w.B = a.B; w.D = a.desc.in_dim; w.w1 = a.off.w1; w.b1 = a.off.b1;
+      w.fn_w = a.desc.use_feature_norm ? a.off.fn_w : -1; w.fn_b = a.desc.use_feature_norm ? a.off.fn_b : -1;
+      const int64_t n_groups = ((a.B + 15) / 16 + 7) / 8;
+      dim3 g2((unsigned)(n_groups < NUM_CU ? n_groups : NUM_CU)), b2(512);
+      const bool relu16 = a.desc.use_relu != 0;
+      const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
+#define WFWD(R, L) do { \
+        static bool attr_set = false; \
+        if (!attr_set) { \
+          hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)); \
+          if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; } \
+          attr_set = true; \
+        } \
+        PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE>), g2, b2, lb, st, w, a); } while (0)
+      if (LN == 0) { if (relu16) WFWD(true, 0); else WFWD(false, 0); }
+      else if (LN == 1) { if (relu16) WFWD(true, 1); else WFWD(false, 1); }
+      else { if (relu16) WFWD(true, 2); else WFWD(false, 2); }
+#undef WFWD
+      MAPPO_CHECK_LAUNCH(who);
+      return MAPPO_OK;
+    }
+  }
 #define FWD2(R, L, W)                                                                                          \
   do {                                                                                                         \
     static bool attr_set = false;                                                                              \

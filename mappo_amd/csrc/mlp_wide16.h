@@ -24,6 +24,27 @@ struct Wide16Args {
   int D, w1, b1, fn_w, fn_b; // offsets into params (fn_* < 0: no feature norm)
 };
 
+
+// Elements k .. k + 3 of a row of D floats (D >= 4) as one 16-byte load that never leaves the row: the load starts at
+// min(k, D - 4) and the lanes are shifted down by the difference, zeros beyond the row.  Rows need 4-byte alignment only
+// (global_load_dwordx4 takes any dword address); with D % 4 == 0 and k % 4 == 0 the shift is 0 or >= 4 (all zero).
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4 ld4_row(const float *row, int k, int D, bool al4) {
+  const int kk = min(k, D - 4), s = k - kk;
+  const f32x4_u l = *reinterpret_cast<const f32x4_u *>(row + kk);
+  f32x4 r;
+  if (al4) {
+    const bool in = s == 0;
+    r[0] = in ? l[0] : 0.f; r[1] = in ? l[1] : 0.f; r[2] = in ? l[2] : 0.f; r[3] = in ? l[3] : 0.f;
+  } else {
+    r[0] = s == 0 ? l[0] : (s == 1 ? l[1] : (s == 2 ? l[2] : (s == 3 ? l[3] : 0.f)));
+    r[1] = s == 0 ? l[1] : (s == 1 ? l[2] : (s == 2 ? l[3] : 0.f));
+    r[2] = s == 0 ? l[2] : (s == 1 ? l[3] : 0.f);
+    r[3] = s == 0 ? l[3] : 0.f;
+  }
+  return r;
+}
+
 // b1'[f] = b1[f] + sum_k W1[f][k] beta0[k]   (64 rows x 8 threads, all 512 threads)
 __device__ __forceinline__ void wide16_fold_bias(const Wide16Args &p, float *sB) {
   const int tid = threadIdx.x, f = tid >> 3, part = tid & 7;
@@ -43,36 +64,33 @@ __device__ __forceinline__ void wide16_fold_bias(const Wide16Args &p, float *sB)
   if (part == 0) sB[f] = p.params[p.b1 + f] + acc;
 }
 
-template <int NCH>
-__global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
-  __shared__ __align__(16) float sW[2][HID * RS16];       // W1' chunk [f][k], double buffered
-  __shared__ __align__(16) float sB[HID];
+// The tile loop of layer 1: for every 16-sample tile of this wave calls tail(acc, i, ok, mean, rstd) with acc = z1 of sample i
+// (accumulator layout: lane (n, q) holds features 16 b + 4 q + r).  sW: [2][64 * RS16] chunk buffers, sB: [64] folded bias.
+template <int NCH, class Tail>
+__device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[HID * RS16], float *sB, Tail &&tail) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = p.D;
   const bool fnorm = p.fn_w >= 0;
-  const bool al4 = (D & 3) == 0 && ((((uintptr_t)p.x) | ((uintptr_t)(p.params + p.w1))) & 15) == 0;
+  const bool al4 = (D & 3) == 0;                             // every 4-column group is inside or outside a row as a whole
   const float inv_D = 1.0f / (float)D;
   wide16_fold_bias(p, sB);
 
   // this thread's share of a weight chunk: row wf, columns 8 wp .. 8 wp + 7 (64 rows x 8 threads)
   const int wf = tid >> 3, wp = tid & 7;
   auto fetch_chunk = [&](int c, float (&w)[8]) {
-    const int k0 = 64 * c + 8 * wp;
-    const float *wrow = p.params + p.w1 + (size_t)wf * D, *src = wrow + k0;
-    if (al4 && k0 + 8 <= D) {
-      const float4 a = reinterpret_cast<const float4 *>(src)[0], b = reinterpret_cast<const float4 *>(src)[1];
-      w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = wrow[min(k0 + j, D - 1)];          // masked below
-    }
+    const float *wrow = p.params + p.w1 + (size_t)wf * D;
+    int wpl = wp;
+    asm volatile("" : "+v"(wrow), "+v"(wpl));                 // per-call addresses (hoisted out of the tile loop they cost 60 VGPRs)
+    const int k0 = 64 * c + 8 * wpl;
+    const f32x4 a = ld4_row(wrow, k0, D, al4), b = ld4_row(wrow, k0 + 4, D, al4);
+    w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
     if (fnorm) {
+      const float *g = p.params + p.fn_w;
+      asm volatile("" : "+s"(g));
+      const f32x4 ga = ld4_row(g, k0, D, al4), gb = ld4_row(g, k0 + 4, D, al4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = (k0 + j < D) ? w[j] * p.params[p.fn_w + min(k0 + j, D - 1)] : 0.f;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = (k0 + j < D) ? w[j] : 0.f;
+      for (int j = 0; j < 4; ++j) { w[j] *= ga[j]; w[4 + j] *= gb[j]; }
     }
   };
   auto store_chunk = [&](int buf, const float (&w)[8]) {
@@ -90,22 +108,16 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
     const bool ok = i < p.B;
     const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
     const float *xr = p.x + row * D;
+    int ql = q;
+    asm volatile("" : "+v"(ql));                               // column offsets / masks per tile, not 32 hoisted address pairs
     // ---- the row block into registers: column 64 c + 16 q + j ----
     float xv[NCH][16];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int k0 = 64 * c + 16 * q;
-      if (al4 && k0 + 16 <= D) {
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) {
-          const float4 t = reinterpret_cast<const float4 *>(xr + k0)[j4];
-          xv[c][4 * j4] = t.x; xv[c][4 * j4 + 1] = t.y; xv[c][4 * j4 + 2] = t.z; xv[c][4 * j4 + 3] = t.w;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) xv[c][j] = xr[min(k0 + j, D - 1)];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) xv[c][j] = (k0 + j < D) ? xv[c][j] : 0.f;
+      for (int j4 = 0; j4 < 4; ++j4) {
+        const f32x4 t = ld4_row(xr, 64 * c + 16 * ql + 4 * j4, D, al4);
+        xv[c][4 * j4] = t[0]; xv[c][4 * j4 + 1] = t[1]; xv[c][4 * j4 + 2] = t[2]; xv[c][4 * j4 + 3] = t[3];
       }
     }
     float w_next[8];
@@ -124,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
       for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          const float d = (64 * c + 16 * q + j < D) ? xv[c][j] - mean : 0.f;
+          const float d = (64 * c + 16 * ql + j < D) ? xv[c][j] - mean : 0.f;
           xv[c][j] = d;
           v4[j & 3] += d * d;
         }
@@ -134,7 +146,6 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) xv[c][j] *= rstd;
     }
-    if (ok && q == 0 && p.mean0) { p.mean0[i] = mean; p.rstd0[i] = rstd; }
     // ---- z1 = b1' + W1' xhat0, chunk by chunk ----
     __syncthreads();                                           // sB ready (first group) / previous group's last chunk consumed
     store_chunk(0, w_next);
@@ -161,11 +172,38 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
         __syncthreads();
       }
     }
+    tail(acc, i, ok, mean, rstd);
+  }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
+  __shared__ __align__(16) float sW[2][HID * RS16];       // W1' chunk [f][k], double buffered
+  __shared__ __align__(16) float sB[HID];
+  const int q = (threadIdx.x & 63) >> 4;
+  wide16_layer1<NCH>(p, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float mean, float rstd) __attribute__((always_inline)) {
     if (ok) {
+      if (q == 0 && p.mean0) { p.mean0[i] = mean; p.rstd0[i] = rstd; }
 #pragma unroll
       for (int b = 0; b < 4; ++b) st4(p.z1 + i * HID + 16 * b + 4 * q, acc[b]);
     }
-  }
+  });
+}
+
+// The whole forward of a wide-input network in one launch (rollout: get_actions / get_values / trunk features): layer 1 as above,
+// then the register-resident 16x16x4 tail of the narrow kernels (mlp_fwd16.h) on the same tile.
+template <bool RELU, int LN, int MODE>
+__global__ __launch_bounds__(512, 2) void wide_forward16_kernel(Wide16Args w, FwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ __align__(16) float sW[2][HID * RS16];
+  __shared__ __align__(16) float sB[HID];
+  stage_all_weights<LN>(lds, p.map, p.params, p.off, p.desc);      // everything but W1 (in_dim > 64: streamed in chunks)
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  float *tZ = lds + p.map.tiles + wave * p.map.wave_stride;
+  wide16_layer1<8>(w, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
+    forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, j, q, tZ);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
