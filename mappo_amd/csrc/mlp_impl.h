@@ -1285,6 +1285,58 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
 #include "mlp_upd16.h"
 #include "mlp_wide16.h"
 
+// ---- launchers of the wide-input kernels (mlp_wide16.h), compiled in their own translation unit (mlp_wide.hip) ----
+int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st);
+int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
+                          const Wide16Args &w, const FwdArgs &a, const char *who);
+int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st);
+
+#ifdef MLP_TU_WIDE
+int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
+  const int nch = (w.D + 63) / 64;
+  dim3 block(512);
+  if (nch <= 2) hipLaunchKernelGGL((wide_l1_fwd16_kernel<2>), grid, block, 0, st, w);
+  else if (nch <= 4) hipLaunchKernelGGL((wide_l1_fwd16_kernel<4>), grid, block, 0, st, w);
+  else if (nch <= 6) hipLaunchKernelGGL((wide_l1_fwd16_kernel<6>), grid, block, 0, st, w);
+  else hipLaunchKernelGGL((wide_l1_fwd16_kernel<8>), grid, block, 0, st, w);
+  return MAPPO_OK;
+}
+
+template <bool R, int L, int MODE, int NWV>
+static int wide16_forward_one(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
+  PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE, NWV>), grid, block, lds_bytes, st, w, a);
+  return MAPPO_OK;
+}
+template <bool R, int L, int MODE>
+static int wide16_forward_nw(bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
+  return small ? wide16_forward_one<R, L, MODE, 4>(grid, block, lds_bytes, st, w, a, who) : wide16_forward_one<R, L, MODE, 8>(grid, block, lds_bytes, st, w, a, who);
+}
+template <bool R, int L>
+static int wide16_forward_mode(int mode, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
+  if (mode == 0) return wide16_forward_nw<R, L, 0>(small, grid, block, lds_bytes, st, w, a, who);
+  if (mode == 1) return wide16_forward_nw<R, L, 1>(small, grid, block, lds_bytes, st, w, a, who);
+  return wide16_forward_nw<R, L, 2>(small, grid, block, lds_bytes, st, w, a, who);
+}
+int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
+                          const Wide16Args &w, const FwdArgs &a, const char *who) {
+  if (ln == 0) return relu ? wide16_forward_mode<true, 0>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 0>(mode, small, grid, block, lds_bytes, st, w, a, who);
+  if (ln == 1) return relu ? wide16_forward_mode<true, 1>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 1>(mode, small, grid, block, lds_bytes, st, w, a, who);
+  return relu ? wide16_forward_mode<true, 2>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 2>(mode, small, grid, block, lds_bytes, st, w, a, who);
+}
+
+int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL(wide_l1_bwd16_kernel<0>, grid, dim3(512), 0, st, w);
+  return MAPPO_OK;
+}
+#endif
+
 #define LDS_LIMIT (160 * 1024)
 #define LDS_STATIC 1024                      // static __shared__ of the kernels (reduction scratch), rounded up
 #define LDS_DYN_MAX (LDS_LIMIT - LDS_STATIC) // what hipFuncAttributeMaxDynamicSharedMemorySize may be raised to
@@ -1654,22 +1706,13 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
       Wide16Args w = {};
       w.params = a.params; w.x = a.x; w.rows = a.rows; w.B = a.B; w.D = a.desc.in_dim; w.w1 = a.off.w1; w.b1 = a.off.b1;
       w.fn_w = a.desc.use_feature_norm ? a.off.fn_w : -1; w.fn_b = a.desc.use_feature_norm ? a.off.fn_b : -1;
-      const int64_t n_groups = ((a.B + 15) / 16 + 7) / 8;
-      dim3 g2((unsigned)(n_groups < NUM_CU ? n_groups : NUM_CU)), b2(512);
-      const bool relu16 = a.desc.use_relu != 0;
-      const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
-#define WFWD(R, L) do { \
-        static bool attr_set = false; \
-        if (!attr_set) { \
-          hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024)); \
-          if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; } \
-          attr_set = true; \
-        } \
-        PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE>), g2, b2, lb, st, w, a); } while (0)
-      if (LN == 0) { if (relu16) WFWD(true, 0); else WFWD(false, 0); }
-      else if (LN == 1) { if (relu16) WFWD(true, 1); else WFWD(false, 1); }
-      else { if (relu16) WFWD(true, 2); else WFWD(false, 2); }
-#undef WFWD
+      // rollout-sized batches: 4-wave workgroups (twice the workgroups, one wave per SIMD) until 8-wave groups fill the chip
+      const int64_t n_tiles16 = (a.B + 15) / 16;
+      const bool small = n_tiles16 < 8 * (int64_t)NUM_CU;
+      const int64_t n_groups = small ? (n_tiles16 + 3) / 4 : (n_tiles16 + 7) / 8;
+      const int64_t cap = small ? 2 * NUM_CU : NUM_CU;
+      dim3 g2((unsigned)(n_groups < cap ? n_groups : cap)), b2(small ? 256 : 512);
+      if (int rcw = wide16_launch_forward(MODE, a.desc.use_relu != 0, LN, small, g2, b2, lb, st, w, a, who)) return rcw;
       MAPPO_CHECK_LAUNCH(who);
       return MAPPO_OK;
     }
@@ -1790,12 +1833,8 @@ static int launch_wide_l1_fwd(const float *params, const mappo_net_desc &d, cons
   w.params = params; w.x = x; w.rows = rows; w.z1 = z1; w.mean0 = mean0; w.rstd0 = rstd0; w.B = B; w.D = d.in_dim;
   w.w1 = o.w1; w.b1 = o.b1; w.fn_w = d.use_feature_norm ? o.fn_w : -1; w.fn_b = d.use_feature_norm ? o.fn_b : -1;
   const int64_t n_groups = ((B + 15) / 16 + 7) / 8;
-  dim3 grid((unsigned)(n_groups < NUM_CU ? n_groups : NUM_CU)), block(512);
-  const int nch = (d.in_dim + 63) / 64;
-  if (nch <= 2) hipLaunchKernelGGL((wide_l1_fwd16_kernel<2>), grid, block, 0, st, w);
-  else if (nch <= 4) hipLaunchKernelGGL((wide_l1_fwd16_kernel<4>), grid, block, 0, st, w);
-  else if (nch <= 6) hipLaunchKernelGGL((wide_l1_fwd16_kernel<6>), grid, block, 0, st, w);
-  else hipLaunchKernelGGL((wide_l1_fwd16_kernel<8>), grid, block, 0, st, w);
+  dim3 grid((unsigned)(n_groups < NUM_CU ? n_groups : NUM_CU));
+  (void)wide16_launch_l1_fwd(w, grid, st);
   MAPPO_CHECK_LAUNCH(who);
   return MAPPO_OK;
 }
@@ -2231,7 +2270,7 @@ extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc 
       w.groups = 8 / w.nca;
       if (rows_max < w.groups) w.groups = 1;
       const int gx = rows_max / w.groups;
-      hipLaunchKernelGGL(wide_l1_bwd16_kernel<0>, dim3((unsigned)gx), dim3(512), 0, as_stream(stream), w);
+      (void)wide16_launch_l1_bwd(w, dim3((unsigned)gx), as_stream(stream));
       MAPPO_CHECK_LAUNCH("wide_l1_backward");
       return MAPPO_OK;
     }

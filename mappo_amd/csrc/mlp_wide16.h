@@ -15,6 +15,14 @@
 //   * output z1 [B][64] row-major (the accumulator layout gives each lane 4 x 16 contiguous bytes).
 #pragma once
 
+// experiment hooks (scripts/exp_build.py): -DWIDE_EXP_NOMFMA replaces the matrix instruction by one add (what is left is the
+// non-MFMA time), -DWIDE_EXP_ROW0 makes every tile read rows 0..15 (no HBM traffic)
+#ifdef WIDE_EXP_NOMFMA
+#define WIDE_MFMA(a, b, c) ((c) + (a) * (b))
+#else
+#define WIDE_MFMA(a, b, c) mfma16(a, b, c)
+#endif
+
 struct Wide16Args {
   const float *params, *x;
   const int32_t *rows;
@@ -26,153 +34,224 @@ struct Wide16Args {
 
 
 // Elements k .. k + 3 of a row of D floats (D >= 4) as one 16-byte load that never leaves the row: the load starts at
-// min(k, D - 4) and the lanes are shifted down by the difference, zeros beyond the row.  Rows need 4-byte alignment only
-// (global_load_dwordx4 takes any dword address); with D % 4 == 0 and k % 4 == 0 the shift is 0 or >= 4 (all zero).
+// min(k, D - 4) (ld4_row_raw) and the lanes are shifted down by the difference, zeros beyond the row (ld4_row_fix — separate,
+// so that the load can stay in flight).  Rows need 4-byte alignment only (global_load_dwordx4 takes any dword address); with
+// D % 4 == 0 and k % 4 == 0 the shift is 0 or >= 4 (all zero).
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ f32x4 ld4_row(const float *row, int k, int D, bool al4) {
-  const int kk = min(k, D - 4), s = k - kk;
-  const f32x4_u l = *reinterpret_cast<const f32x4_u *>(row + kk);
+__device__ __forceinline__ f32x4 ld4_row_raw(const float *row, int k, int D) {
+  const f32x4_u l = *reinterpret_cast<const f32x4_u *>(row + min(k, D - 4));
+  f32x4 r; r[0] = l[0]; r[1] = l[1]; r[2] = l[2]; r[3] = l[3];
+  return r;
+}
+__device__ __forceinline__ f32x4 ld4_row_fix(const f32x4 l, int k, int D, bool al4) {
+  // bit masks, not selects: nested selects on a per-lane shift come out as divergent branches
+  const int s = k - min(k, D - 4);
+  const uint32_t l0 = __float_as_uint(l[0]), l1 = __float_as_uint(l[1]), l2 = __float_as_uint(l[2]), l3 = __float_as_uint(l[3]);
+  const uint32_t m0 = s == 0 ? ~0u : 0u;
   f32x4 r;
   if (al4) {
-    const bool in = s == 0;
-    r[0] = in ? l[0] : 0.f; r[1] = in ? l[1] : 0.f; r[2] = in ? l[2] : 0.f; r[3] = in ? l[3] : 0.f;
+    r[0] = __uint_as_float(l0 & m0); r[1] = __uint_as_float(l1 & m0); r[2] = __uint_as_float(l2 & m0); r[3] = __uint_as_float(l3 & m0);
   } else {
-    r[0] = s == 0 ? l[0] : (s == 1 ? l[1] : (s == 2 ? l[2] : (s == 3 ? l[3] : 0.f)));
-    r[1] = s == 0 ? l[1] : (s == 1 ? l[2] : (s == 2 ? l[3] : 0.f));
-    r[2] = s == 0 ? l[2] : (s == 1 ? l[3] : 0.f);
-    r[3] = s == 0 ? l[3] : 0.f;
+    const uint32_t m1 = s == 1 ? ~0u : 0u, m2 = s == 2 ? ~0u : 0u, m3 = s == 3 ? ~0u : 0u;
+    r[0] = __uint_as_float((l0 & m0) | (l1 & m1) | (l2 & m2) | (l3 & m3));
+    r[1] = __uint_as_float((l1 & m0) | (l2 & m1) | (l3 & m2));
+    r[2] = __uint_as_float((l2 & m0) | (l3 & m1));
+    r[3] = __uint_as_float(l3 & m0);
   }
   return r;
 }
+__device__ __forceinline__ f32x4 ld4_row(const float *row, int k, int D, bool al4) { return ld4_row_fix(ld4_row_raw(row, k, D), k, D, al4); }
 
-// b1'[f] = b1[f] + sum_k W1[f][k] beta0[k]   (64 rows x 8 threads, all 512 threads)
+// b1'[f] = b1[f] + sum_k W1[f][k] beta0[k]   (64 rows x TPR threads: the whole workgroup)
+template <int TPR>
 __device__ __forceinline__ void wide16_fold_bias(const Wide16Args &p, float *sB) {
-  const int tid = threadIdx.x, f = tid >> 3, part = tid & 7;
+  const int tid = threadIdx.x, f = tid / TPR, part = tid % TPR;
   float acc = 0.f;
   if (p.fn_b >= 0) {
     const float *w = p.params + p.w1 + (size_t)f * p.D, *bt = p.params + p.fn_b;
-    for (int k0 = part; k0 < p.D; k0 += 64) {
+    for (int k0 = part; k0 < p.D; k0 += 8 * TPR) {
       float wv[8], bv[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const int k = min(k0 + 8 * j, p.D - 1); wv[j] = w[k]; bv[j] = bt[k]; }
+      for (int j = 0; j < 8; ++j) { const int k = min(k0 + TPR * j, p.D - 1); wv[j] = w[k]; bv[j] = bt[k]; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) if (k0 + 8 * j < p.D) acc += wv[j] * bv[j];
+      for (int j = 0; j < 8; ++j) if (k0 + TPR * j < p.D) acc += wv[j] * bv[j];
     }
   }
 #pragma unroll
-  for (int off = 1; off < 8; off <<= 1) acc += __shfl_xor(acc, off, WAVE);
+  for (int off = 1; off < TPR; off <<= 1) acc += __shfl_xor(acc, off, WAVE);
   if (part == 0) sB[f] = p.params[p.b1 + f] + acc;
 }
 
-// The tile loop of layer 1: for every 16-sample tile of this wave calls tail(acc, i, ok, mean, rstd) with acc = z1 of sample i
-// (accumulator layout: lane (n, q) holds features 16 b + 4 q + r).  sW: [2][64 * RS16] chunk buffers, sB: [64] folded bias.
-template <int NCH, class Tail>
+__device__ __forceinline__ f32x4 ld4u(const float *ptr) {             // 16-byte load from a 4-byte aligned address
+  const f32x4_u l = *reinterpret_cast<const f32x4_u *>(ptr);
+  f32x4 r; r[0] = l[0]; r[1] = l[1]; r[2] = l[2]; r[3] = l[3];
+  return r;
+}
+
+// The tile loop of layer 1 for a workgroup of NW waves (8 or 4): for every 16-sample tile of this wave calls
+// tail(acc, i, ok, mean, rstd) with acc = z1 of sample i (accumulator layout: lane (n, q) holds features 16 b + 4 q + r).
+// sW: [2][64 * RS16] chunk buffers, sB: [64] folded bias.
+//   * The kernel is bound by instruction issue, not by HBM or the matrix pipe alone (fp32 MFMA shares the vector ALU: with the
+//     matrix instruction replaced by an add AND all rows read from L2 the first version still took 68 % of its time), so every
+//     per-element operation is kept off the main path: the 1/std factor is applied to the 16 accumulators instead of the 16 NCH
+//     inputs (z1 = b1' + rstd (W1' (x - mean))), the statistics run on 4-wide vectors (packed fp32 instructions), row-end
+//     clamping / masking only exists for the LAST 64-column chunk (the others use immediate offsets from one row pointer).
+//   * The row block of the NEXT tile is loaded into the registers of the current one chunk by chunk, as the MFMAs of a chunk
+//     retire its 16 registers: HBM latency and bandwidth run under the matrix work with no second register set.
+template <int NCH, int NW, class Tail>
 __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[HID * RS16], float *sB, Tail &&tail) {
+  constexpr int TPR = NW, CW = 64 / NW, CV = CW / 4;          // threads per weight row, floats (vectors) per thread and chunk
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = p.D;
   const bool fnorm = p.fn_w >= 0;
   const bool al4 = (D & 3) == 0;                             // every 4-column group is inside or outside a row as a whole
   const float inv_D = 1.0f / (float)D;
-  wide16_fold_bias(p, sB);
+  const int64_t n_tiles = (p.B + 15) / 16;
+  const int64_t n_groups = (n_tiles + NW - 1) / NW;           // NW tiles (one per wave) share the weight stream
+  const int c_last = (D + 63) / 64 - 1;                       // the chunk that holds the row end
+  if ((int64_t)blockIdx.x >= n_groups) return;                // (uniform; the launch never has more workgroups than groups)
+  wide16_fold_bias<TPR>(p, sB);
 
-  // this thread's share of a weight chunk: row wf, columns 8 wp .. 8 wp + 7 (64 rows x 8 threads)
-  const int wf = tid >> 3, wp = tid & 7;
-  auto fetch_chunk = [&](int c, float (&w)[8]) {
-    const float *wrow = p.params + p.w1 + (size_t)wf * D;
-    int wpl = wp;
-    asm volatile("" : "+v"(wrow), "+v"(wpl));                 // per-call addresses (hoisted out of the tile loop they cost 60 VGPRs)
-    const int k0 = 64 * c + 8 * wpl;
-    const f32x4 a = ld4_row(wrow, k0, D, al4), b = ld4_row(wrow, k0 + 4, D, al4);
-    w[0] = a[0]; w[1] = a[1]; w[2] = a[2]; w[3] = a[3]; w[4] = b[0]; w[5] = b[1]; w[6] = b[2]; w[7] = b[3];
-    if (fnorm) {
-      const float *g = p.params + p.fn_w;
-      asm volatile("" : "+s"(g));
-      const f32x4 ga = ld4_row(g, k0, D, al4), gb = ld4_row(g, k0 + 4, D, al4);
+  // this thread's share of a weight chunk: row wf, columns CW wp .. CW wp + CW - 1
+  const int wf = tid / TPR, wp = tid % TPR;
+  auto fetch_chunk = [&](int c, f32x4 (&w)[CV]) {
+    int wfl = wf, wpl = wp;
+    asm volatile("" : "+v"(wfl), "+v"(wpl));                  // per-call addresses (hoisted out of the tile loop they cost 60 VGPRs)
+    const float *wrow = p.params + p.w1 + (size_t)wfl * D, *g = p.params + p.fn_w;
+    const int k0 = 64 * c + CW * wpl;
+    if (c < c_last) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { w[j] *= ga[j]; w[4 + j] *= gb[j]; }
+      for (int j4 = 0; j4 < CV; ++j4) w[j4] = ld4u(wrow + k0 + 4 * j4);
+      if (fnorm) {
+#pragma unroll
+        for (int j4 = 0; j4 < CV; ++j4) w[j4] *= ld4u(g + k0 + 4 * j4);
+      }
+    } else {
+#pragma unroll
+      for (int j4 = 0; j4 < CV; ++j4) w[j4] = ld4_row(wrow, k0 + 4 * j4, D, al4);
+      if (fnorm) {
+#pragma unroll
+        for (int j4 = 0; j4 < CV; ++j4) w[j4] *= ld4_row(g, k0 + 4 * j4, D, al4);
+      }
     }
   };
-  auto store_chunk = [&](int buf, const float (&w)[8]) {
-    float *dst = &sW[buf][wf * RS16 + 8 * wp];
-    *reinterpret_cast<float4 *>(dst) = make_float4(w[0], w[1], w[2], w[3]);
-    *reinterpret_cast<float4 *>(dst + 4) = make_float4(w[4], w[5], w[6], w[7]);
+  auto store_chunk = [&](int buf, const f32x4 (&w)[CV]) {
+    float *dst = &sW[buf][wf * RS16 + CW * wp];
+#pragma unroll
+    for (int j4 = 0; j4 < CV; ++j4) st4(dst + 4 * j4, w[j4]);
+  };
+  auto row_ptr = [&](int64_t grp) {
+    const int64_t i = (grp * NW + wave) * 16 + n;
+#ifdef WIDE_EXP_ROW0
+    const int64_t row = n + 0 * i;
+#else
+    const int64_t row = i < p.B ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
+#endif
+    return p.x + row * D;
+  };
+  f32x4 xq[NCH][4];                                           // the row block: xq[c][j4][t] = column 64 c + 16 j4 + 4 q + t (a row's 64 B per load)
+  auto load_rows = [&](const float *xr, int c) {              // raw (ld4_row_fix is applied to the last chunk when the tile starts)
+    int ql = q;
+    asm volatile("" : "+v"(ql));                              // (offsets recomputed per call, not kept as address pairs)
+    if (c < c_last) {
+      const float *xc = xr + 4 * ql;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4u(xc + 64 * c + 16 * j4);
+    } else if (c == c_last) {
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_raw(xr, 64 * c + 16 * j4 + 4 * ql, D);
+    }
   };
 
-  const int64_t n_tiles = (p.B + 15) / 16;
-  const int64_t n_groups = (n_tiles + 7) / 8;                 // 8 tiles (one per wave) share the weight stream
-  const int n_chunks = (D + 63) / 64;
-  for (int64_t grp = blockIdx.x; grp < n_groups; grp += gridDim.x) {
-    const int64_t tile = grp * 8 + wave;
-    const int64_t i = tile * 16 + n;
-    const bool ok = i < p.B;
-    const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
-    const float *xr = p.x + row * D;
-    int ql = q;
-    asm volatile("" : "+v"(ql));                               // column offsets / masks per tile, not 32 hoisted address pairs
-    // ---- the row block into registers: column 64 c + 16 q + j ----
-    float xv[NCH][16];
+  int64_t grp = blockIdx.x;
+  {
+    const float *xr = row_ptr(grp);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) {
-        const f32x4 t = ld4_row(xr, 64 * c + 16 * ql + 4 * j4, D, al4);
-        xv[c][4 * j4] = t[0]; xv[c][4 * j4 + 1] = t[1]; xv[c][4 * j4 + 2] = t[2]; xv[c][4 * j4 + 3] = t[3];
-      }
+      for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = f32x4{0.f, 0.f, 0.f, 0.f};     // chunks beyond the row stay zero
+      load_rows(xr, c);
     }
-    float w_next[8];
-    fetch_chunk(0, w_next);
-    // ---- LayerNorm statistics over the D inputs (exact two-pass on the registers) ----
+  }
+  f32x4 w_next[CV];
+  fetch_chunk(0, w_next);
+  for (;;) {
+    const int64_t i = (grp * NW + wave) * 16 + n;
+    const bool ok = i < p.B;
+    const int64_t next = grp + gridDim.x;
+    const bool has_next = next < n_groups;
+    const float *xr_next = row_ptr(has_next ? next : grp);
+    int ql = q;
+    asm volatile("" : "+v"(ql));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (c == c_last) {
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_fix(xq[c][j4], 64 * c + 16 * j4 + 4 * ql, D, al4);
+      }
+    // ---- LayerNorm statistics over the D inputs (exact two-pass on the registers); the inputs become x - mean ----
     float mean = 0.f, rstd = 1.f;
     if (fnorm) {
-      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < NCH; ++c)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s4[j & 3] += xv[c][j];
+        for (int j4 = 0; j4 < 4; ++j4) s4 += xq[c][j4];
       mean = quad_sum16((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_D;
-      float v4[4] = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 mean4 = {mean, mean, mean, mean};
+      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < NCH; ++c)
+      for (int c = 0; c < NCH; ++c) {
+        if (c < c_last) {
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const float d = (64 * c + 16 * ql + j < D) ? xv[c][j] - mean : 0.f;
-          xv[c][j] = d;
-          v4[j & 3] += d * d;
+          for (int j4 = 0; j4 < 4; ++j4) { const f32x4 d = xq[c][j4] - mean4; xq[c][j4] = d; v4 += d * d; }
+        } else if (c == c_last) {
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) {
+            f32x4 d = xq[c][j4] - mean4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = (64 * c + 16 * j4 + 4 * ql + t < D) ? d[t] : 0.f;
+            xq[c][j4] = d; v4 += d * d;
+          }
         }
+      }
       rstd = 1.0f / sqrtf(quad_sum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * inv_D + LN_EPS);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) xv[c][j] *= rstd;
     }
-    // ---- z1 = b1' + W1' xhat0, chunk by chunk ----
-    __syncthreads();                                           // sB ready (first group) / previous group's last chunk consumed
-    store_chunk(0, w_next);
+    // ---- z1 = b1' + rstd W1' (x - mean), chunk by chunk ----
+    store_chunk(0, w_next);                                    // (buffer 0 is free: the barrier after the previous tile's last chunk)
     f32x4 acc[4];
 #pragma unroll
-    for (int bo = 0; bo < 4; ++bo) acc[bo] = ld4(sB + 16 * bo + 4 * q);
+    for (int bo = 0; bo < 4; ++bo) acc[bo] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      if (c < n_chunks) {
-        if (c + 1 < n_chunks) fetch_chunk(c + 1, w_next);
-        const float *Wc = &sW[c & 1][n * RS16 + 16 * q];
+      if (c <= c_last) {
+        const bool last = c == c_last;
+        if (!last) fetch_chunk(c + 1, w_next);
+        else if (has_next) fetch_chunk(0, w_next);             // chunk 0 for the next tile
+        const float *Wc = &sW[c & 1][n * RS16 + 4 * q];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           f32x4 a[4];
 #pragma unroll
-          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + 16 * bo * RS16 + 4 * jj);
+          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + 16 * bo * RS16 + 16 * jj);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int bo = 0; bo < 4; ++bo) acc[bo] = mfma16(a[bo][t], xv[c][4 * jj + t], acc[bo]);
+            for (int bo = 0; bo < 4; ++bo) acc[bo] = WIDE_MFMA(a[bo][t], xq[c][jj][t], acc[bo]);
         }
-        if (c + 1 < n_chunks) store_chunk((c + 1) & 1, w_next);
+        if (has_next) load_rows(xr_next, c);                   // these 16 registers are free: the next tile's columns
+        if (!last) store_chunk((c + 1) & 1, w_next);
         __syncthreads();
       }
     }
+    const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) acc[bo] = acc[bo] * rstd4 + ld4(sB + 16 * bo + 4 * q);
     tail(acc, i, ok, mean, rstd);
+    if (!has_next) break;
+    grp = next;
   }
 }
 
@@ -181,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   __shared__ __align__(16) float sW[2][HID * RS16];       // W1' chunk [f][k], double buffered
   __shared__ __align__(16) float sB[HID];
   const int q = (threadIdx.x & 63) >> 4;
-  wide16_layer1<NCH>(p, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float mean, float rstd) __attribute__((always_inline)) {
+  wide16_layer1<NCH, 8>(p, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float mean, float rstd) __attribute__((always_inline)) {
     if (ok) {
       if (q == 0 && p.mean0) { p.mean0[i] = mean; p.rstd0[i] = rstd; }
 #pragma unroll
@@ -192,8 +271,8 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
 
 // The whole forward of a wide-input network in one launch (rollout: get_actions / get_values / trunk features): layer 1 as above,
 // then the register-resident 16x16x4 tail of the narrow kernels (mlp_fwd16.h) on the same tile.
-template <bool RELU, int LN, int MODE>
-__global__ __launch_bounds__(512, 2) void wide_forward16_kernel(Wide16Args w, FwdArgs p) {
+template <bool RELU, int LN, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void wide_forward16_kernel(Wide16Args w, FwdArgs p) {
   extern __shared__ __align__(16) float lds[];
   __shared__ __align__(16) float sW[2][HID * RS16];
   __shared__ __align__(16) float sB[HID];
@@ -201,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void wide_forward16_kernel(Wide16Args w, Fw
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float *tZ = lds + p.map.tiles + wave * p.map.wave_stride;
-  wide16_layer1<8>(w, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
+  wide16_layer1<8, NW>(w, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
     forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, j, q, tZ);
   });
 }
@@ -215,8 +294,9 @@ __global__ __launch_bounds__(512, 2) void wide_forward16_kernel(Wide16Args w, Fw
 // re-read dz1 once per 64-column chunk).  A workgroup walks 16-sample tiles; wave w owns the 64-column chunk w % NCA of W1's
 // gradient (64 accumulator registers) for the tiles of its tile group w / NCA:
 //   * A operand = dz1^T: lane (m, q) needs dz1[16 bf + m][4 q .. 4 q + 3] — ONE 16-byte load from the feature-major array;
-//   * B operand = xhat0^T of the chunk: lane (n, q) reads x[row 4 q + j][chunk + 16 bk + n] (64-byte segments; every input
-//     element is read exactly once by exactly one wave) and normalises it with the sample's (mean0, rstd0);
+//   * B operand = xhat0^T of the chunk: lane (n, q) reads x[row 4 q + j][chunk + 4 n .. 4 n + 3] as ONE 16-byte load (the
+//     accumulator block bk holds column chunk + 4 n + bk: a row's 64 columns are 256 contiguous bytes over the 16 lanes; every
+//     input element is read exactly once by exactly one wave) and normalises it with the sample's (mean0, rstd0);
 //   * 64 MFMAs per tile and wave; the next tile's operands are fetched under them.
 // The transform above runs per wave in registers at the end (it is linear, so it commutes with the slab reduction); one slab
 // row per (workgroup, tile group).
@@ -233,7 +313,7 @@ struct WideBwd16Args {
 
 struct WideBwdOps {
   f32x4 a[4];                // dz1[16 bf + m][4 q + j]
-  float b[4][4];             // x[row 4 q + j][chunk + 16 bk + n]  (b[j][bk])
+  f32x4 b[4];                // x[row 4 q + j][chunk + 4 n + bk]  (b[j][bk]; raw load, see ld4_row_raw)
   f32x4 mean, rstd;          // of samples 4 q + j
 };
 
@@ -261,8 +341,7 @@ __device__ __forceinline__ void wide_bwd_fetch(WideBwdOps &o, const WideBwd16Arg
     const int64_t s = min(s0 + j, p.B - 1);
     const int64_t row = p.rows ? (int64_t)p.rows[s] : s;
     const float *xr = p.x + row * p.D;
-#pragma unroll
-    for (int bk = 0; bk < 4; ++bk) o.b[j][bk] = xr[min(c0 + 16 * bk + n, p.D - 1)];
+    o.b[j] = ld4_row_raw(xr, c0 + 4 * n, p.D);
   }
 }
 
@@ -276,6 +355,10 @@ __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) 
   const bool active = tg < p.groups && c0 < p.D;
   const bool fnorm = p.fn_w >= 0;
   const bool al = (p.B & 3) == 0 && (((uintptr_t)p.wide_ws) & 15) == 0;
+  const bool al4 = (p.D & 3) == 0;
+  bool kv4[4];
+#pragma unroll
+  for (int bk = 0; bk < 4; ++bk) kv4[bk] = c0 + 4 * n + bk < p.D;
   f32x4 G[4][4];
   float db[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -292,12 +375,10 @@ __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) 
       if (tile + stride < n_tiles) wide_bwd_fetch(nxt, p, tile + stride, c0, n, q, al);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        const f32x4 raw = ld4_row_fix(cur.b[j], c0 + 4 * n, p.D, al4);        // zeros beyond the row
         float b[4];
 #pragma unroll
-        for (int bk = 0; bk < 4; ++bk) {
-          const float raw = (c0 + 16 * bk + n < p.D) ? cur.b[j][bk] : 0.f;
-          b[bk] = fnorm ? ((c0 + 16 * bk + n < p.D) ? (raw - cur.mean[j]) * cur.rstd[j] : 0.f) : raw;
-        }
+        for (int bk = 0; bk < 4; ++bk) b[bk] = fnorm ? (kv4[bk] ? (raw[bk] - cur.mean[j]) * cur.rstd[j] : 0.f) : raw[bk];
 #pragma unroll
         for (int bf = 0; bf < 4; ++bf) {
           db[bf] += cur.a[bf][j];
@@ -321,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) 
   float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int bk = 0; bk < 4; ++bk) {
-    const int k = c0 + 16 * bk + n;
+    const int k = c0 + 4 * n + bk;
     const bool kv = k < p.D;
     const int kc = kv ? k : p.D - 1;
     const float gam = fnorm ? p.params[p.fn_w + kc] : 1.f, bet = fnorm ? p.params[p.fn_b + kc] : 0.f;
