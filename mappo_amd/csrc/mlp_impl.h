@@ -36,6 +36,8 @@
 // Limits of this build: hidden == 64, out_dim <= 32, layer_N <= 2, in_dim <= 512.
 #include "mlp_core.h"
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 #ifdef MLP_TU_MAIN
 extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
@@ -1292,14 +1294,24 @@ int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, di
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st);
 
 #ifdef MLP_TU_WIDE
+template <int NCH>
+static int wide16_l1_fwd_one(const Wide16Args &w, dim3 grid, size_t lds_bytes, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_fwd16_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
+    if (e_ != hipSuccess) { mappo_set_error("wide_l1_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wide_l1_fwd16_kernel<NCH>), grid, dim3(512), lds_bytes, st, w);
+  return MAPPO_OK;
+}
 int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
   const int nch = (w.D + 63) / 64;
-  dim3 block(512);
-  if (nch <= 2) hipLaunchKernelGGL((wide_l1_fwd16_kernel<2>), grid, block, 0, st, w);
-  else if (nch <= 4) hipLaunchKernelGGL((wide_l1_fwd16_kernel<4>), grid, block, 0, st, w);
-  else if (nch <= 6) hipLaunchKernelGGL((wide_l1_fwd16_kernel<6>), grid, block, 0, st, w);
-  else hipLaunchKernelGGL((wide_l1_fwd16_kernel<8>), grid, block, 0, st, w);
-  return MAPPO_OK;
+  const size_t lds_bytes = sizeof(float) * ((size_t)HID * (64 * nch + 4) + HID);      // W1' whole + folded bias
+  if (nch <= 2) return wide16_l1_fwd_one<2>(w, grid, lds_bytes, st);
+  if (nch <= 4) return wide16_l1_fwd_one<4>(w, grid, lds_bytes, st);
+  if (nch <= 6) return wide16_l1_fwd_one<6>(w, grid, lds_bytes, st);
+  return wide16_l1_fwd_one<8>(w, grid, lds_bytes, st);
 }
 
 template <bool R, int L, int MODE, int NWV>
@@ -1332,7 +1344,9 @@ int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, di
 }
 
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL(wide_l1_bwd16_kernel<0>, grid, dim3(512), 0, st, w);
+  const bool fn = w.fn_w >= 0;
+  if (w.rows) { if (fn) hipLaunchKernelGGL((wide_l1_bwd16_kernel<true, true>), grid, dim3(512), 0, st, w); else hipLaunchKernelGGL((wide_l1_bwd16_kernel<false, true>), grid, dim3(512), 0, st, w); }
+  else { if (fn) hipLaunchKernelGGL((wide_l1_bwd16_kernel<true, false>), grid, dim3(512), 0, st, w); else hipLaunchKernelGGL((wide_l1_bwd16_kernel<false, false>), grid, dim3(512), 0, st, w); }
   return MAPPO_OK;
 }
 #endif
@@ -1812,7 +1826,23 @@ static bool upd16x_eligible(const mappo_net_desc &d, bool actor) {
   if (e && e[0] == '0') return false;
   return d.in_dim > MAXD && d.in_dim <= 512 && d.layer_N <= 1 && !d.recurrent && (actor ? d.out_dim <= 16 : d.out_dim == 1);
 }
-static int64_t wide_z1_offset(int64_t B) { return ((int64_t)(HID + 2) * B + 3) & ~(int64_t)3; }     // dz1 [64][B] | mean0 | rstd0 | (pad) | z1 [B][64]
+static int64_t wide_z1_offset(int64_t B) { return wide16_z1_offset(B); }     // workspace layout: mlp_wide16.h (>= the [64][B] | mean0 | rstd0 of the round-1 kernels)
+
+// Which layout the last producer left in a wide workspace (dz1 blocked per tile + padded statistics: the 16x16x4 path; or the
+// round-1 kernels' feature-major [64][B] | mean0 [B] | rstd0 [B]) — mappo_wide_l1_backward picks the matching consumer.  Host
+// side, keyed by the workspace pointer: producer and consumer are enqueued by the same thread in stream order (and a graph
+// capture records the kernels chosen here).
+static std::mutex g_wide_layout_mu;
+static std::unordered_map<const void *, int> g_wide_layout;
+static void wide_layout_set(const void *ws, int blocked) {
+  std::lock_guard<std::mutex> lk(g_wide_layout_mu);
+  g_wide_layout[ws] = blocked;
+}
+static int wide_layout_get(const void *ws) {
+  std::lock_guard<std::mutex> lk(g_wide_layout_mu);
+  auto it = g_wide_layout.find(ws);
+  return it == g_wide_layout.end() ? 0 : it->second;
+}
 static size_t upd16x_lds_floats(const mappo_net_desc &d, bool actor) {
   if (actor) return d.layer_N > 0 ? L16<1, 1, true, true>::TOTAL : L16<0, 1, true, true>::TOTAL;
   return d.layer_N > 0 ? L16<1, 2, true, true>::TOTAL : L16<0, 2, true, true>::TOTAL;
@@ -1834,7 +1864,7 @@ static int launch_wide_l1_fwd(const float *params, const mappo_net_desc &d, cons
   w.w1 = o.w1; w.b1 = o.b1; w.fn_w = d.use_feature_norm ? o.fn_w : -1; w.fn_b = d.use_feature_norm ? o.fn_b : -1;
   const int64_t n_groups = ((B + 15) / 16 + 7) / 8;
   dim3 grid((unsigned)(n_groups < NUM_CU ? n_groups : NUM_CU));
-  (void)wide16_launch_l1_fwd(w, grid, st);
+  if (int rcl = wide16_launch_l1_fwd(w, grid, st)) return rcl;
   MAPPO_CHECK_LAUNCH(who);
   return MAPPO_OK;
 }
@@ -1890,9 +1920,10 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
     // wide inputs: layer-1 forward as its own kernel (mlp_wide16.h), then the 16-sample-tile update kernel from z1 on; the
     // caller's mappo_wide_l1_backward turns dz1 + the row statistics into the W1 / feature-norm gradients
     MAPPO_REQUIRE(a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
-    if (int rcw = launch_wide_l1_fwd(a.params, d, a.off, a.x, a.rows, a.B, a.wide_ws + wide_z1_offset(a.B), a.wide_ws + (int64_t)HID * a.B,
-                                     a.wide_ws + (int64_t)(HID + 1) * a.B, st, who))
+    if (int rcw = launch_wide_l1_fwd(a.params, d, a.off, a.x, a.rows, a.B, a.wide_ws + wide_z1_offset(a.B), a.wide_ws + 64 * wide16_bp(a.B),
+                                     a.wide_ws + 65 * wide16_bp(a.B), st, who))
       return rcw;
+    wide_layout_set(a.wide_ws, 1);
     Upd16Args a16 = {};
     a16.u = a;
     if (int rc16 = prep16x(a16, HEAD == 1, who)) return rc16;
@@ -1923,6 +1954,7 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
     MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
     a.red_base = a.off.b1;
     MAPPO_REQUIRE(a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
+    wide_layout_set(a.wide_ws, 0);                              // feature-major dz1 [64][B] | mean0 | rstd0
     const int p_span = a.p_red - a.red_base;
     a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * p_span) ? 2 : 1;
     MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * p_span, "%s: reduction buffer too small", who);
@@ -2256,8 +2288,7 @@ extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc 
   MAPPO_REQUIRE(desc->in_dim > MAXD, "wide_l1_backward: in_dim %d is handled inside the update kernels", desc->in_dim);
   MAPPO_REQUIRE(params && x && wide_ws && slabs && B > 0, "wide_l1_backward: bad arguments");
   {
-    const char *e16 = getenv("MAPPO_UPD16");
-    if (!(e16 && e16[0] == '0') && desc->in_dim <= 512) {
+    if (wide_layout_get(wide_ws) == 1) {
       // 16x16x4 kernel (mlp_wide16.h): raw products, every input element read once
       const NetOff o = net_offsets(*desc);
       MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + o.total <= slab_stride, "wide_l1_backward: slab column range");

@@ -419,7 +419,7 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   const UpdArgs &p = P.u;
   typedef L16<LN, HEAD, WIDE, XL1> M;
   // XL1 workspace (mappo_wide_workspace_floats): dz1 [64][B] feature-major | mean0 [B] | rstd0 [B] | z1 [B][64]
-  const float *z1 = XL1 ? p.wide_ws + ((66 * p.B + 3) & ~(int64_t)3) : nullptr;
+  const float *z1 = XL1 ? p.wide_ws + 66 * ((p.B + 15) & ~(int64_t)15) : nullptr;      // wide16_z1_offset (mlp_wide16.h)
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), n_waves = blockDim.x / WAVE;
@@ -757,15 +757,14 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     STAMP(9);   // d xhat1
     ln_act_bwd16<RELU>(dx, xh, mean1, rstd1, pos1);            // dx = dz1
     if constexpr (XL1) {
-      // dz1 goes to HBM feature-major for wide_l1_bwd_kernel (W1 / feature-norm gradients: 64 x in_dim accumulators do not
+      // dz1 goes to HBM (blocked feature-major per tile) for wide_l1_bwd16_kernel (W1 / feature-norm gradients: 64 x in_dim accumulators do not
       // fit a wave); the bias gradient accumulates per lane
-      float *dz1T = p.wide_ws;
-      const int64_t col = tile * 16 + n;
+      float *dz1b = p.wide_ws + tile * 1024 + n;               // blocked [tile][64 features][16 samples] (mlp_wide16.h)
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (live) dz1T[(int64_t)(16 * b + 4 * q + i) * p.B + col] = dx[b][i];
+          if (live) dz1b[(16 * b + 4 * q + i) * 16] = dx[b][i];
           gB1x[b][i] += dx[b][i];
         }
       STAMP(10);

@@ -255,18 +255,142 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
   }
 }
 
+// wide_l1_fwd16_kernel — training-sized batches: W1' (gamma folded in) is staged ONCE per workgroup into LDS, whole
+// ([64][64 nch + 4] floats: 132 KB at in_dim 512), so the tile loop has no barrier and no weight traffic at all: the 8 waves walk
+// their tiles independently (one wave's row loads and statistics run under the other waves' MFMAs).  Streaming the chunks
+// through a double buffer (wide16_layer1, kept for the rollout kernel where a workgroup sees too few tiles to amortise the
+// staging) left every chunk waiting for an L2 round trip behind a workgroup barrier: 4 us per chunk against 2 us of MFMA.
 template <int NCH>
 __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
-  __shared__ __align__(16) float sW[2][HID * RS16];       // W1' chunk [f][k], double buffered
-  __shared__ __align__(16) float sB[HID];
-  const int q = (threadIdx.x & 63) >> 4;
-  wide16_layer1<NCH, 8>(p, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float mean, float rstd) __attribute__((always_inline)) {
+  extern __shared__ __align__(16) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = p.D;
+  const bool fnorm = p.fn_w >= 0;
+  const bool al4 = (D & 3) == 0;
+  const float inv_D = 1.0f / (float)D;
+  const int c_last = (D + 63) / 64 - 1;
+  const int RSW = 64 * (c_last + 1) + 4;                       // row stride of W1' in LDS (== 4 mod 64: conflict-free 16-byte reads)
+  float *sW = lds, *sB = lds + HID * RSW;
+  // ---- stage W1' = W1 gamma0 (zeros beyond the row) and the folded bias ----
+  {
+    const int nv = RSW / 4 - 1;                                // 16-byte groups per row
+    for (int e = tid; e < HID * nv; e += blockDim.x) {
+      const int f = e / nv, k = 4 * (e - f * nv);
+      f32x4 w = ld4_row(p.params + p.w1 + (size_t)f * D, k, D, al4);
+      if (fnorm) w *= ld4_row(p.params + p.fn_w, k, D, al4);
+      st4(sW + f * RSW + k, w);
+    }
+    wide16_fold_bias<8>(p, sB);
+  }
+  __syncthreads();
+
+  const int64_t n_tiles = (p.B + 15) / 16, stride = (int64_t)gridDim.x * 8;
+  auto row_ptr = [&](int64_t tile) {
+    const int64_t i = tile * 16 + n;
+#ifdef WIDE_EXP_ROW0
+    const int64_t row = n + 0 * i;
+#else
+    const int64_t row = i < p.B ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
+#endif
+    return p.x + row * D;
+  };
+  f32x4 xq[NCH][4];                                           // the row block: xq[c][j4][t] = column 64 c + 16 j4 + 4 q + t (a row's 64 B per load)
+  auto load_rows = [&](const float *xr, int c) {              // raw (ld4_row_fix is applied to the last chunk when the tile starts)
+    int ql = q;
+    asm volatile("" : "+v"(ql));                              // (offsets recomputed per call, not kept as address pairs)
+    if (c < c_last) {
+      const float *xc = xr + 4 * ql;
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4u(xc + 64 * c + 16 * j4);
+    } else if (c == c_last) {
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_raw(xr, 64 * c + 16 * j4 + 4 * ql, D);
+    }
+  };
+  int64_t tile = (int64_t)blockIdx.x * 8 + wave;
+  if (tile >= n_tiles) return;
+  {
+    const float *xr = row_ptr(tile);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = f32x4{0.f, 0.f, 0.f, 0.f};     // chunks beyond the row stay zero
+      load_rows(xr, c);
+    }
+  }
+  for (;;) {
+    const int64_t i = tile * 16 + n;
+    const bool ok = i < p.B;
+    const int64_t next = tile + stride;
+    const bool has_next = next < n_tiles;
+    const float *xr_next = row_ptr(has_next ? next : tile);
+    int ql = q;
+    asm volatile("" : "+v"(ql));
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+      if (c == c_last) {
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_fix(xq[c][j4], 64 * c + 16 * j4 + 4 * ql, D, al4);
+      }
+    // ---- LayerNorm statistics over the D inputs (exact two-pass on the registers); the inputs become x - mean ----
+    float mean = 0.f, rstd = 1.f;
+    if (fnorm) {
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4) s4 += xq[c][j4];
+      mean = quad_sum16((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_D;
+      const f32x4 mean4 = {mean, mean, mean, mean};
+      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        if (c < c_last) {
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) { const f32x4 d = xq[c][j4] - mean4; xq[c][j4] = d; v4 += d * d; }
+        } else if (c == c_last) {
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) {
+            f32x4 d = xq[c][j4] - mean4;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = (64 * c + 16 * j4 + 4 * ql + t < D) ? d[t] : 0.f;
+            xq[c][j4] = d; v4 += d * d;
+          }
+        }
+      }
+      rstd = 1.0f / sqrtf(quad_sum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * inv_D + LN_EPS);
+    }
+    // ---- z1 = b1' + rstd W1' (x - mean) ----
+    f32x4 acc[4];
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) acc[bo] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      if (c <= c_last) {
+        const float *Wc = sW + n * RSW + 4 * q + 64 * c;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          f32x4 a[4];
+#pragma unroll
+          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + 16 * bo * RSW + 16 * jj);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) acc[bo] = WIDE_MFMA(a[bo][t], xq[c][jj][t], acc[bo]);
+        }
+        if (has_next) load_rows(xr_next, c);                   // these 16 registers are free: the next tile's columns
+      }
+    }
+    const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
     if (ok) {
       if (q == 0 && p.mean0) { p.mean0[i] = mean; p.rstd0[i] = rstd; }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) st4(p.z1 + i * HID + 16 * b + 4 * q, acc[b]);
+      for (int b = 0; b < 4; ++b) st4(p.z1 + i * HID + 16 * b + 4 * q, acc[b] * rstd4 + ld4(sB + 16 * b + 4 * q));
     }
-  });
+    if (!has_next) break;
+    tile = next;
+  }
 }
 
 // The whole forward of a wide-input network in one launch (rollout: get_actions / get_values / trunk features): layer 1 as above,
@@ -286,25 +410,36 @@ __global__ __launch_bounds__(64 * NW, 2) void wide_forward16_kernel(Wide16Args w
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// wide_l1_bwd16_kernel — weight gradient of layer 1 and the feature-norm gradients for in_dim 65..512 from dz1 (feature-major
-// [64][B]) and the row statistics the forward left:
+// wide_l1_bwd16_kernel — weight gradient of layer 1 and the feature-norm gradients for in_dim 65..512 from dz1 and the row
+// statistics the forward left (workspace layout below):
 //     G[f][k] = sum_s dz1[f][s] xhat0[k][s]   (RAW product: xhat0 without the affine),   db[f] = sum_s dz1[f][s]
 //     dW1 = gamma0[k] G + beta0[k] db[f],   dgamma0[k] = sum_f W1[f][k] G[f][k],   dbeta0[k] = sum_f W1[f][k] db[f]
 // (the raw-product identities of mlp_impl.h: no dX = W1^T dz1 pass — half the MFMA work of the round-1 kernel, which also
 // re-read dz1 once per 64-column chunk).  A workgroup walks 16-sample tiles; wave w owns the 64-column chunk w % NCA of W1's
 // gradient (64 accumulator registers) for the tiles of its tile group w / NCA:
-//   * A operand = dz1^T: lane (m, q) needs dz1[16 bf + m][4 q .. 4 q + 3] — ONE 16-byte load from the feature-major array;
+//   * A operand = dz1^T: lane (m, q) needs dz1[16 bf + m][4 q .. 4 q + 3] — ONE 16-byte load; dz1 is stored BLOCKED,
+//     [tile][64 features][16 samples], so that such a load instruction covers 1 KB of contiguous memory (feature-major [64][B]
+//     made every lane touch its own cache line: 1.46 -> 1.18 ms at B = 1.6 M);
 //   * B operand = xhat0^T of the chunk: lane (n, q) reads x[row 4 q + j][chunk + 4 n .. 4 n + 3] as ONE 16-byte load (the
 //     accumulator block bk holds column chunk + 4 n + bk: a row's 64 columns are 256 contiguous bytes over the 16 lanes; every
 //     input element is read exactly once by exactly one wave) and normalises it with the sample's (mean0, rstd0);
-//   * 64 MFMAs per tile and wave; the next tile's operands are fetched under them.
+//   * 64 MFMAs per tile and wave; the next tile's operands are fetched under them.  Like the forward kernel this one is bound by
+//     instruction issue (fp32 MFMA shares the vector ALU), so the tile loop is specialised: full tiles only (the one partial
+//     tile of a batch is a separate masked step), row gather or not, row-end chunk or not — addresses advance by pointer
+//     increments, the per-element work is two packed instructions per sample.
 // The transform above runs per wave in registers at the end (it is linear, so it commutes with the slab reduction); one slab
 // row per (workgroup, tile group).
+//
+// Workspace of the 16x16x4 wide path (floats; Bp = B rounded up to 16):
+//     [0, 64 Bp)  dz1 blocked [tile][64][16]  |  [64 Bp, 65 Bp) mean0  |  [65 Bp, 66 Bp) rstd0  |  [66 Bp, 66 Bp + 64 B)  z1 [B][64]
 // ------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int64_t wide16_bp(int64_t B) { return (B + 15) & ~(int64_t)15; }
+__host__ __device__ __forceinline__ int64_t wide16_z1_offset(int64_t B) { return 66 * wide16_bp(B); }
+
 struct WideBwd16Args {
   const float *params, *x;
   const int32_t *rows;
-  const float *wide_ws;      // dz1 [64][B] | mean0 [B] | rstd0 [B]
+  const float *wide_ws;      // see above
   float *slabs;
   int64_t slab_stride, slab_col0, B;
   int D, w1, fn_w, fn_b;     // fn_* < 0: no feature norm
@@ -317,35 +452,11 @@ struct WideBwdOps {
   f32x4 mean, rstd;          // of samples 4 q + j
 };
 
-__device__ __forceinline__ void wide_bwd_fetch(WideBwdOps &o, const WideBwd16Args &p, int64_t tile, int c0, int n, int q, bool al) {
-  const int64_t base = tile * 16, s0 = base + 4 * q;
-  const float *dz = p.wide_ws, *st = p.wide_ws + (int64_t)HID * p.B;
-  const bool full = base + 16 <= p.B;
-  if (full && al) {
-#pragma unroll
-    for (int bf = 0; bf < 4; ++bf) o.a[bf] = ld4(dz + (int64_t)(16 * bf + n) * p.B + s0);
-    o.mean = ld4(st + s0);
-    o.rstd = ld4(st + p.B + s0);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int64_t s = min(s0 + j, p.B - 1);
-      const bool ok = s0 + j < p.B;
-#pragma unroll
-      for (int bf = 0; bf < 4; ++bf) { const float v = dz[(int64_t)(16 * bf + n) * p.B + s]; o.a[bf][j] = ok ? v : 0.f; }
-      o.mean[j] = st[s]; o.rstd[j] = st[p.B + s];
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t s = min(s0 + j, p.B - 1);
-    const int64_t row = p.rows ? (int64_t)p.rows[s] : s;
-    const float *xr = p.x + row * p.D;
-    o.b[j] = ld4_row_raw(xr, c0 + 4 * n, p.D);
-  }
-}
-
-template <int UNUSED>            // (a template only so that the header may be included by every translation unit)
+// One kernel instance has ONE copy of the tile loop (several specialised copies under uniform branches made the compiler keep
+// the 64 accumulators in different registers per copy and shuffle / spill them at the joins): feature norm and row gather are
+// template parameters chosen by the host; the row-end chunk and the one partial tile of a batch are small uniform branches
+// around the per-element fix-ups only.
+template <bool FNORM, bool GATHER>
 __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) {
   __shared__ float sDb[8][HID];
   const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
@@ -353,51 +464,122 @@ __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) 
   const int chunk = wave % p.nca, tg = wave / p.nca;
   const int c0 = 64 * chunk;
   const bool active = tg < p.groups && c0 < p.D;
-  const bool fnorm = p.fn_w >= 0;
-  const bool al = (p.B & 3) == 0 && (((uintptr_t)p.wide_ws) & 15) == 0;
+  const bool fnorm = FNORM;
+  const bool edge = c0 + 64 > p.D;                             // this wave's chunk holds the row end: clamped loads, masked columns
   const bool al4 = (p.D & 3) == 0;
-  bool kv4[4];
-#pragma unroll
-  for (int bk = 0; bk < 4; ++bk) kv4[bk] = c0 + 4 * n + bk < p.D;
+  const int kcol = c0 + 4 * n, kcl = min(kcol, p.D - 4);       // this lane's 4 columns; where its 16-byte load starts
+  const int64_t Bp = wide16_bp(p.B);
+  const float *dz = p.wide_ws, *st_mean = p.wide_ws + 64 * Bp, *st_rstd = p.wide_ws + 65 * Bp;
   f32x4 G[4][4];
   float db[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int bf = 0; bf < 4; ++bf)
 #pragma unroll
-    for (int bk = 0; bk < 4; ++bk) { G[bf][bk][0] = 0.f; G[bf][bk][1] = 0.f; G[bf][bk][2] = 0.f; G[bf][bk][3] = 0.f; }
-  const int64_t n_tiles = (p.B + 15) / 16;
+    for (int bk = 0; bk < 4; ++bk) G[bf][bk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int64_t n_full = p.B >> 4;                             // full tiles; tile n_full is the partial one (if any)
+  const int64_t n_tiles = (p.B + 15) >> 4;
   const int64_t stride = (int64_t)gridDim.x * p.groups;
-  if (active) {
-    int64_t tile = (int64_t)blockIdx.x * p.groups + tg;
-    WideBwdOps cur, nxt;
-    if (tile < n_tiles) wide_bwd_fetch(cur, p, tile, c0, n, q, al);
-    for (; tile < n_tiles; tile += stride) {
-      if (tile + stride < n_tiles) wide_bwd_fetch(nxt, p, tile + stride, c0, n, q, al);
+  const int64_t tile0 = (int64_t)blockIdx.x * p.groups + tg;
+
+  auto fetch_rows = [&](int (&ridx)[4], int64_t tile) __attribute__((always_inline)) {
+    int64_t s0 = tile * 16 + 4 * q;
+    if (tile == n_full) {                                      // partial tile: stay inside rows[]
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ridx[j] = p.rows[min(s0 + j, p.B - 1)];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ridx[j] = p.rows[s0 + j];
+    }
+  };
+  auto fetch = [&](WideBwdOps &o, int64_t tile, const int (&ridx)[4]) __attribute__((always_inline)) {
+    const float *dzt = dz + tile * 1024 + n * 16 + 4 * q;      // (padded to whole tiles: always in bounds)
+#pragma unroll
+    for (int bf = 0; bf < 4; ++bf) o.a[bf] = ld4(dzt + 256 * bf);
+    o.mean = ld4(st_mean + tile * 16 + 4 * q);
+    o.rstd = ld4(st_rstd + tile * 16 + 4 * q);
+    if (GATHER) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.b[j] = ld4u(p.x + (int64_t)ridx[j] * p.D + kcl);
+    } else if (tile == n_full) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.b[j] = ld4u(p.x + min(tile * 16 + 4 * q + j, p.B - 1) * p.D + kcl);
+    } else {
+      const float *xr = p.x + (tile * 16 + 4 * q) * p.D + kcl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o.b[j] = ld4u(xr + (int64_t)j * p.D);
+    }
+  };
+  // one tile: 64 MFMAs; 2 packed instructions per sample for (x - mean) rstd; the bias gradient (the same for every chunk) is
+  // accumulated by the chunk-0 wave alone
+  auto compute = [&](WideBwdOps &o, int64_t tile) __attribute__((always_inline)) {
+    if (tile == n_full) {                                      // partial tile: samples beyond the batch contribute nothing
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const f32x4 raw = ld4_row_fix(cur.b[j], c0 + 4 * n, p.D, al4);        // zeros beyond the row
-        float b[4];
+        const bool v = tile * 16 + 4 * q + j < p.B;
 #pragma unroll
-        for (int bk = 0; bk < 4; ++bk) b[bk] = fnorm ? (kv4[bk] ? (raw[bk] - cur.mean[j]) * cur.rstd[j] : 0.f) : raw[bk];
+        for (int bf = 0; bf < 4; ++bf) o.a[bf][j] = v ? o.a[bf][j] : 0.f;
+        o.mean[j] = v ? o.mean[j] : 0.f; o.rstd[j] = v ? o.rstd[j] : 0.f;
+      }
+    }
+    if (edge) {                                                // zeros beyond the row
 #pragma unroll
-        for (int bf = 0; bf < 4; ++bf) {
-          db[bf] += cur.a[bf][j];
+      for (int j = 0; j < 4; ++j) o.b[j] = ld4_row_fix(o.b[j], kcol, p.D, al4);
+    }
 #pragma unroll
-          for (int bk = 0; bk < 4; ++bk) G[bf][bk] = mfma16(cur.a[bf][j], b[bk], G[bf][bk]);
+    for (int j = 0; j < 4; ++j) {
+      f32x4 xh = o.b[j];
+      if (fnorm) {
+        const f32x4 m4 = {o.mean[j], o.mean[j], o.mean[j], o.mean[j]}, r4 = {o.rstd[j], o.rstd[j], o.rstd[j], o.rstd[j]};
+        xh = (xh - m4) * r4;
+        if (edge) {
+#pragma unroll
+          for (int bk = 0; bk < 4; ++bk) xh[bk] = (kcol + bk < p.D) ? xh[bk] : 0.f;
         }
       }
-      cur = nxt;
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf)
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk) G[bf][bk] = WIDE_MFMA(o.a[bf][j], xh[bk], G[bf][bk]);
+    }
+    if (chunk == 0) {
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf) db[bf] += (o.a[bf][0] + o.a[bf][1]) + (o.a[bf][2] + o.a[bf][3]);
+    }
+  };
+  if (active) {
+    // two operand sets (the next tile's loads run under this tile's MFMAs); with a row gather the indices are fetched one
+    // tile further ahead, so that the x loads never wait for them
+    int64_t tile = tile0;
+    WideBwdOps o0, o1;
+    int r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+    if (GATHER) {
+      if (tile < n_tiles) fetch_rows(r0, tile);
+      if (tile + stride < n_tiles) fetch_rows(r1, tile + stride);
+    }
+    if (tile < n_tiles) fetch(o0, tile, r0);
+    while (tile < n_tiles) {
+      if (tile + stride < n_tiles) fetch(o1, tile + stride, r1);
+      if (GATHER && tile + 2 * stride < n_tiles) fetch_rows(r0, tile + 2 * stride);
+      compute(o0, tile);
+      tile += stride;
+      if (tile >= n_tiles) break;
+      if (tile + stride < n_tiles) fetch(o0, tile + stride, r0);
+      if (GATHER && tile + 2 * stride < n_tiles) fetch_rows(r1, tile + 2 * stride);
+      compute(o1, tile);
+      tile += stride;
     }
   }
-  // ---- raw products -> gradients, per wave (db: lane (m, q) holds the sum over its samples of dz1[16 bf + m]) ----
+  // ---- bias gradient of the tile group: lane (m, q) of the chunk-0 wave holds the sum over its samples of dz1[16 bf + m] ----
+  if (active && chunk == 0) {
 #pragma unroll
-  for (int bf = 0; bf < 4; ++bf) db[bf] = quad_sum16(db[bf]);
-  if (q == 0) {
-#pragma unroll
-    for (int bf = 0; bf < 4; ++bf) sDb[wave][16 * bf + n] = db[bf];
+    for (int bf = 0; bf < 4; ++bf) {
+      const float d = quad_sum16(db[bf]);
+      if (q == 0) sDb[tg][16 * bf + n] = d;
+    }
   }
-  wave_lds_sync();
+  __syncthreads();
   if (!active) return;
+  // ---- raw products -> gradients, per wave ----
   float *slab = p.slabs + (size_t)((int64_t)blockIdx.x * p.groups + tg) * p.slab_stride + p.slab_col0;
   float dgam[4] = {0.f, 0.f, 0.f, 0.f}, dbet[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -408,16 +590,16 @@ __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) 
     const float gam = fnorm ? p.params[p.fn_w + kc] : 1.f, bet = fnorm ? p.params[p.fn_b + kc] : 0.f;
 #pragma unroll
     for (int bf = 0; bf < 4; ++bf) {
-      const f32x4 dbv = ld4(&sDb[wave][16 * bf + 4 * q]);
+      const f32x4 dbq = ld4(&sDb[tg][16 * bf + 4 * q]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int f = 16 * bf + 4 * q + i;
         const float g = G[bf][bk][i];
         if (fnorm) {
           const float w = p.params[p.w1 + f * p.D + kc];
-          dgam[bk] += w * g; dbet[bk] += w * dbv[i];
+          dgam[bk] += w * g; dbet[bk] += w * dbq[i];
         }
-        if (kv) slab[p.w1 + f * p.D + k] = gam * g + bet * dbv[i];
+        if (kv) slab[p.w1 + f * p.D + k] = gam * g + bet * dbq[i];
       }
     }
     if (fnorm) {
