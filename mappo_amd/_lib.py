@@ -87,6 +87,7 @@ SIGNATURES = {
     "mappo_clip_adam": (C.c_int, [_P, _P, _P, _P, C.POINTER(_I64), _I32, _P, _P, _P, _P, _P, _P]),
     "mappo_reduce_clip_adam": (C.c_int, [_P, _I32, _I64, _P, _P, _P, _P, C.POINTER(_I64), _I32, _P, _P, _P, _P, _P, _P]),
     "mappo_mpe_spread_reset": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _U64, _P]),
+    "mappo_synth_smac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, C.c_float, C.c_float, _U64, _P, _P]),
     "mappo_mpe_spread_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32, _I32, _U64, _P]),
     "mappo_profile_arm": (C.c_int, [_I32, _P, _P]),
     "mappo_selftest_mfma": (C.c_int, [_P, _P, _P, _P]),

@@ -1285,7 +1285,10 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
 
 #include "mlp_upd2.h"
 #include "mlp_upd16.h"
+#include "mlp_wide16_args.h"
+#ifdef MLP_TU_WIDE
 #include "mlp_wide16.h"
+#endif
 
 // ---- launchers of the wide-input kernels (mlp_wide16.h), compiled in their own translation unit (mlp_wide.hip) ----
 int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st);
@@ -1314,21 +1317,23 @@ int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
   return wide16_l1_fwd_one<8>(w, grid, lds_bytes, st);
 }
 
-template <bool R, int L, int MODE, int NWV>
+template <bool R, int L, int MODE, int NWV, int NCH>
 static int wide16_forward_one(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE, NWV, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
     if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
     attr_set = true;
   }
   const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
-  PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE, NWV>), grid, block, lds_bytes, st, w, a);
+  PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE, NWV, NCH>), grid, block, lds_bytes, st, w, a);
   return MAPPO_OK;
 }
 template <bool R, int L, int MODE>
 static int wide16_forward_nw(bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
-  return small ? wide16_forward_one<R, L, MODE, 4>(grid, block, lds_bytes, st, w, a, who) : wide16_forward_one<R, L, MODE, 8>(grid, block, lds_bytes, st, w, a, who);
+  const bool half = w.D <= 256;                               // row block registers for 4 chunks instead of 8
+  if (small) return half ? wide16_forward_one<R, L, MODE, 4, 4>(grid, block, lds_bytes, st, w, a, who) : wide16_forward_one<R, L, MODE, 4, 8>(grid, block, lds_bytes, st, w, a, who);
+  return half ? wide16_forward_one<R, L, MODE, 8, 4>(grid, block, lds_bytes, st, w, a, who) : wide16_forward_one<R, L, MODE, 8, 8>(grid, block, lds_bytes, st, w, a, who);
 }
 template <bool R, int L>
 static int wide16_forward_mode(int mode, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {

@@ -14,6 +14,7 @@
 //     fetched (global -> registers) under the 64 MFMAs of chunk c and stored before the single barrier per chunk;
 //   * output z1 [B][64] row-major (the accumulator layout gives each lane 4 x 16 contiguous bytes).
 #pragma once
+#include "mlp_wide16_args.h"
 
 // experiment hooks (scripts/exp_build.py): -DWIDE_EXP_NOMFMA replaces the matrix instruction by one add (what is left is the
 // non-MFMA time), -DWIDE_EXP_ROW0 makes every tile read rows 0..15 (no HBM traffic)
@@ -22,16 +23,6 @@
 #else
 #define WIDE_MFMA(a, b, c) mfma16(a, b, c)
 #endif
-
-struct Wide16Args {
-  const float *params, *x;
-  const int32_t *rows;
-  float *z1;                 // [B][64]
-  float *mean0, *rstd0;      // [B] each (may be NULL: rollout forward)
-  int64_t B;
-  int D, w1, b1, fn_w, fn_b; // offsets into params (fn_* < 0: no feature norm)
-};
-
 
 // Elements k .. k + 3 of a row of D floats (D >= 4) as one 16-byte load that never leaves the row: the load starts at
 // min(k, D - 4) (ld4_row_raw) and the lanes are shifted down by the difference, zeros beyond the row (ld4_row_fix — separate,
@@ -88,18 +79,19 @@ __device__ __forceinline__ f32x4 ld4u(const float *ptr) {             // 16-byte
   return r;
 }
 
-// The tile loop of layer 1 for a workgroup of NW waves (8 or 4): for every 16-sample tile of this wave calls
-// tail(acc, i, ok, mean, rstd) with acc = z1 of sample i (accumulator layout: lane (n, q) holds features 16 b + 4 q + r).
-// sW: [2][64 * RS16] chunk buffers, sB: [64] folded bias.
-//   * The kernel is bound by instruction issue, not by HBM or the matrix pipe alone (fp32 MFMA shares the vector ALU: with the
-//     matrix instruction replaced by an add AND all rows read from L2 the first version still took 68 % of its time), so every
-//     per-element operation is kept off the main path: the 1/std factor is applied to the 16 accumulators instead of the 16 NCH
-//     inputs (z1 = b1' + rstd (W1' (x - mean))), the statistics run on 4-wide vectors (packed fp32 instructions), row-end
-//     clamping / masking only exists for the LAST 64-column chunk (the others use immediate offsets from one row pointer).
-//   * The row block of the NEXT tile is loaded into the registers of the current one chunk by chunk, as the MFMAs of a chunk
-//     retire its 16 registers: HBM latency and bandwidth run under the matrix work with no second register set.
-template <int NCH, int NW, class Tail>
-__device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[HID * RS16], float *sB, Tail &&tail) {
+// The tile loop of layer 1 for a workgroup of NW waves (8 or 4), W1' streamed through LDS in 64-column chunks (rollout-sized
+// batches: a workgroup sees one or two tiles per wave, too few to amortise staging all of W1): for every 16-sample tile of this
+// wave calls tail(acc, i, ok, mean, rstd) with acc = z1 of sample i (accumulator layout: lane (n, q) holds features
+// 16 b + 4 q + r).  sW: [2][64 * RS16] chunk buffers, sB: [64] folded bias.  pre() runs once, after the first loads are issued
+// (the caller's own staging overlaps their latency).
+//   * Latency is what matters here (a launch is a handful of chunks long): the chunk fetches run TWO chunks ahead of the MFMAs
+//     (two register sets, the LDS tile stays double buffered), the folded bias b1' = b1 + W1 beta0 is accumulated by the
+//     staging threads from the chunks they load anyway (no separate pass over W1), and the row block is read before anything
+//     else.
+//   * Per-element work is kept off the main path as in the training kernel below: 1/std on the 16 accumulators, packed
+//     statistics, row-end clamping / masking only for the last chunk.
+template <int NCH, int NW, class Pre, class Tail>
+__device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[HID * RS16], float *sB, Pre &&pre, Tail &&tail) {
   constexpr int TPR = NW, CW = 64 / NW, CV = CW / 4;          // threads per weight row, floats (vectors) per thread and chunk
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -109,31 +101,47 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
   const float inv_D = 1.0f / (float)D;
   const int64_t n_tiles = (p.B + 15) / 16;
   const int64_t n_groups = (n_tiles + NW - 1) / NW;           // NW tiles (one per wave) share the weight stream
-  const int c_last = (D + 63) / 64 - 1;                       // the chunk that holds the row end
-  if ((int64_t)blockIdx.x >= n_groups) return;                // (uniform; the launch never has more workgroups than groups)
-  wide16_fold_bias<TPR>(p, sB);
+  const int c_last = (D + 63) / 64 - 1;                       // the chunk that holds the row end (>= 1: in_dim > 64)
 
   // this thread's share of a weight chunk: row wf, columns CW wp .. CW wp + CW - 1
   const int wf = tid / TPR, wp = tid % TPR;
-  auto fetch_chunk = [&](int c, f32x4 (&w)[CV]) {
+  float bacc = 0.f;                                           // this thread's part of (W1 beta0)[wf]
+  auto fetch_chunk = [&](int c, f32x4 (&w)[CV], bool with_bias) {
     int wfl = wf, wpl = wp;
     asm volatile("" : "+v"(wfl), "+v"(wpl));                  // per-call addresses (hoisted out of the tile loop they cost 60 VGPRs)
-    const float *wrow = p.params + p.w1 + (size_t)wfl * D, *g = p.params + p.fn_w;
+    const float *wrow = p.params + p.w1 + (size_t)wfl * D, *g = p.params + p.fn_w, *bt = p.params + p.fn_b;
     const int k0 = 64 * c + CW * wpl;
+    f32x4 gm[CV], be[CV];
     if (c < c_last) {
 #pragma unroll
       for (int j4 = 0; j4 < CV; ++j4) w[j4] = ld4u(wrow + k0 + 4 * j4);
       if (fnorm) {
 #pragma unroll
-        for (int j4 = 0; j4 < CV; ++j4) w[j4] *= ld4u(g + k0 + 4 * j4);
+        for (int j4 = 0; j4 < CV; ++j4) gm[j4] = ld4u(g + k0 + 4 * j4);
+        if (with_bias) {
+#pragma unroll
+          for (int j4 = 0; j4 < CV; ++j4) be[j4] = ld4u(bt + k0 + 4 * j4);
+        }
       }
     } else {
 #pragma unroll
       for (int j4 = 0; j4 < CV; ++j4) w[j4] = ld4_row(wrow, k0 + 4 * j4, D, al4);
       if (fnorm) {
 #pragma unroll
-        for (int j4 = 0; j4 < CV; ++j4) w[j4] *= ld4_row(g, k0 + 4 * j4, D, al4);
+        for (int j4 = 0; j4 < CV; ++j4) gm[j4] = ld4_row(g, k0 + 4 * j4, D, al4);
+        if (with_bias) {
+#pragma unroll
+          for (int j4 = 0; j4 < CV; ++j4) be[j4] = ld4_row(bt, k0 + 4 * j4, D, al4);
+        }
       }
+    }
+    if (fnorm) {
+      if (with_bias) {
+#pragma unroll
+        for (int j4 = 0; j4 < CV; ++j4) { const f32x4 t = w[j4] * be[j4]; bacc += (t[0] + t[1]) + (t[2] + t[3]); }
+      }
+#pragma unroll
+      for (int j4 = 0; j4 < CV; ++j4) w[j4] *= gm[j4];
     }
   };
   auto store_chunk = [&](int buf, const f32x4 (&w)[CV]) {
@@ -143,11 +151,7 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
   };
   auto row_ptr = [&](int64_t grp) {
     const int64_t i = (grp * NW + wave) * 16 + n;
-#ifdef WIDE_EXP_ROW0
-    const int64_t row = n + 0 * i;
-#else
     const int64_t row = i < p.B ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
-#endif
     return p.x + row * D;
   };
   f32x4 xq[NCH][4];                                           // the row block: xq[c][j4][t] = column 64 c + 16 j4 + 4 q + t (a row's 64 B per load)
@@ -165,7 +169,8 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
   };
 
   int64_t grp = blockIdx.x;
-  {
+  const bool any = grp < n_groups;                            // (uniform; the launch never has more workgroups than groups)
+  if (any) {
     const float *xr = row_ptr(grp);
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
@@ -174,8 +179,11 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
       load_rows(xr, c);
     }
   }
-  f32x4 w_next[CV];
-  fetch_chunk(0, w_next);
+  f32x4 wA[CV], wB[CV];                                       // chunks c (even) / c (odd) on their way to LDS
+  bool first = true;
+  if (any) { fetch_chunk(0, wA, true); fetch_chunk(1, wB, true); }
+  pre();
+  if (!any) return;
   for (;;) {
     const int64_t i = (grp * NW + wave) * 16 + n;
     const bool ok = i < p.B;
@@ -219,7 +227,7 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
       rstd = 1.0f / sqrtf(quad_sum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * inv_D + LN_EPS);
     }
     // ---- z1 = b1' + rstd W1' (x - mean), chunk by chunk ----
-    store_chunk(0, w_next);                                    // (buffer 0 is free: the barrier after the previous tile's last chunk)
+    store_chunk(0, wA);                                        // (buffer 0 is free: the barrier after the previous tile's last chunk)
     f32x4 acc[4];
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo) acc[bo] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -227,9 +235,7 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (c <= c_last) {
-        const bool last = c == c_last;
-        if (!last) fetch_chunk(c + 1, w_next);
-        else if (has_next) fetch_chunk(0, w_next);             // chunk 0 for the next tile
+        if (c + 2 <= c_last) { if (c & 1) fetch_chunk(c + 2, wB, first); else fetch_chunk(c + 2, wA, first); }
         const float *Wc = &sW[c & 1][n * RS16 + 4 * q];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -242,13 +248,23 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
             for (int bo = 0; bo < 4; ++bo) acc[bo] = WIDE_MFMA(a[bo][t], xq[c][jj][t], acc[bo]);
         }
         if (has_next) load_rows(xr_next, c);                   // these 16 registers are free: the next tile's columns
-        if (!last) store_chunk((c + 1) & 1, w_next);
+        if (c + 1 <= c_last) {
+          if (c & 1) store_chunk(0, wA); else store_chunk(1, wB);          // chunk c + 1 (set (c + 1) & 1) into buffer (c + 1) & 1
+          if (first && c + 1 == c_last) {                      // every chunk has been fetched: the folded bias of row wf
+            float t = bacc;
+#pragma unroll
+            for (int off = 1; off < TPR; off <<= 1) t += __shfl_xor(t, off, WAVE);
+            if (wp == 0) sB[wf] = p.params[p.b1 + wf] + (p.fn_b >= 0 ? t : 0.f);
+          }
+        }
         __syncthreads();
       }
     }
     const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
 #pragma unroll
     for (int bo = 0; bo < 4; ++bo) acc[bo] = acc[bo] * rstd4 + ld4(sB + 16 * bo + 4 * q);
+    if (has_next) { fetch_chunk(0, wA, false); fetch_chunk(1, wB, false); }       // re-prime the stream under the tail
+    first = false;
     tail(acc, i, ok, mean, rstd);
     if (!has_next) break;
     grp = next;
@@ -395,18 +411,19 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
 
 // The whole forward of a wide-input network in one launch (rollout: get_actions / get_values / trunk features): layer 1 as above,
 // then the register-resident 16x16x4 tail of the narrow kernels (mlp_fwd16.h) on the same tile.
-template <bool RELU, int LN, int MODE, int NW>
+template <bool RELU, int LN, int MODE, int NW, int NCH>
 __global__ __launch_bounds__(64 * NW, 2) void wide_forward16_kernel(Wide16Args w, FwdArgs p) {
   extern __shared__ __align__(16) float lds[];
   __shared__ __align__(16) float sW[2][HID * RS16];
   __shared__ __align__(16) float sB[HID];
-  stage_all_weights<LN>(lds, p.map, p.params, p.off, p.desc);      // everything but W1 (in_dim > 64: streamed in chunks)
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float *tZ = lds + p.map.tiles + wave * p.map.wave_stride;
-  wide16_layer1<8, NW>(w, sW, sB, [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
-    forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, j, q, tZ);
-  });
+  wide16_layer1<NCH, NW>(w, sW, sB,
+    [&]() __attribute__((always_inline)) { stage_all_weights<LN>(lds, p.map, p.params, p.off, p.desc); },    // everything but W1 (streamed in chunks)
+    [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
+      forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, j, q, tZ);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
@@ -433,19 +450,6 @@ __global__ __launch_bounds__(64 * NW, 2) void wide_forward16_kernel(Wide16Args w
 // Workspace of the 16x16x4 wide path (floats; Bp = B rounded up to 16):
 //     [0, 64 Bp)  dz1 blocked [tile][64][16]  |  [64 Bp, 65 Bp) mean0  |  [65 Bp, 66 Bp) rstd0  |  [66 Bp, 66 Bp + 64 B)  z1 [B][64]
 // ------------------------------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int64_t wide16_bp(int64_t B) { return (B + 15) & ~(int64_t)15; }
-__host__ __device__ __forceinline__ int64_t wide16_z1_offset(int64_t B) { return 66 * wide16_bp(B); }
-
-struct WideBwd16Args {
-  const float *params, *x;
-  const int32_t *rows;
-  const float *wide_ws;      // see above
-  float *slabs;
-  int64_t slab_stride, slab_col0, B;
-  int D, w1, fn_w, fn_b;     // fn_* < 0: no feature norm
-  int nca, groups;           // chunk owners per tile group (power of two >= number of chunks), tile groups (nca * groups <= 8)
-};
-
 struct WideBwdOps {
   f32x4 a[4];                // dz1[16 bf + m][4 q + j]
   f32x4 b[4];                // x[row 4 q + j][chunk + 4 n + bk]  (b[j][bk]; raw load, see ld4_row_raw)
@@ -547,25 +551,32 @@ __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) 
     }
   };
   if (active) {
-    // two operand sets (the next tile's loads run under this tile's MFMAs); with a row gather the indices are fetched one
-    // tile further ahead, so that the x loads never wait for them
+    // three operand sets: the loads of a tile are issued two tiles (~2 x 1.2 us of MFMA) before its products; with a row gather
+    // the indices are fetched one tile further ahead still, so that the x loads never wait for them
     int64_t tile = tile0;
-    WideBwdOps o0, o1;
-    int r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0};
+    WideBwdOps o0, o1, o2;
+    int r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
     if (GATHER) {
       if (tile < n_tiles) fetch_rows(r0, tile);
       if (tile + stride < n_tiles) fetch_rows(r1, tile + stride);
+      if (tile + 2 * stride < n_tiles) fetch_rows(r2, tile + 2 * stride);
     }
     if (tile < n_tiles) fetch(o0, tile, r0);
+    if (tile + stride < n_tiles) fetch(o1, tile + stride, r1);
     while (tile < n_tiles) {
-      if (tile + stride < n_tiles) fetch(o1, tile + stride, r1);
-      if (GATHER && tile + 2 * stride < n_tiles) fetch_rows(r0, tile + 2 * stride);
+      if (tile + 2 * stride < n_tiles) fetch(o2, tile + 2 * stride, r2);
+      if (GATHER && tile + 3 * stride < n_tiles) fetch_rows(r0, tile + 3 * stride);
       compute(o0, tile);
       tile += stride;
       if (tile >= n_tiles) break;
-      if (tile + stride < n_tiles) fetch(o0, tile + stride, r0);
-      if (GATHER && tile + 2 * stride < n_tiles) fetch_rows(r1, tile + 2 * stride);
+      if (tile + 2 * stride < n_tiles) fetch(o0, tile + 2 * stride, r0);
+      if (GATHER && tile + 3 * stride < n_tiles) fetch_rows(r1, tile + 3 * stride);
       compute(o1, tile);
+      tile += stride;
+      if (tile >= n_tiles) break;
+      if (tile + 2 * stride < n_tiles) fetch(o1, tile + 2 * stride, r1);
+      if (GATHER && tile + 3 * stride < n_tiles) fetch_rows(r2, tile + 3 * stride);
+      compute(o2, tile);
       tile += stride;
     }
   }

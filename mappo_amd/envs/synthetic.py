@@ -65,6 +65,7 @@ class SyntheticSMACEnv:
         self.share_observation_space = [[share_dim] for _ in range(num_agents)]
         self.action_space = [Discrete(n_actions) for _ in range(num_agents)]
         self.dead = torch.zeros(self.N, self.M, dtype=torch.bool, device=self.device)
+        self.seed = int(seed)
         with torch.cuda.device(self.device):
             torch.cuda.manual_seed(seed)
 
@@ -80,8 +81,25 @@ class SyntheticSMACEnv:
         self.dead.zero_()
         return self._draw()
 
+    def _fused_state(self):
+        # buffers of the one-launch step (csrc/synth_env.hip); the runner copies what it is handed before the next step
+        if not hasattr(self, "_f"):
+            N, M, dev = self.N, self.M, self.device
+            self._f = dict(obs=torch.empty(N, M, self.D, device=dev), share=torch.empty(N, M, self.S, device=dev),
+                           avail=torch.empty(N, M, self.A, device=dev), rew=torch.empty(N, device=dev),
+                           dones=torch.zeros(N, M, dtype=torch.bool, device=dev), bad=torch.zeros(N, M, dtype=torch.bool, device=dev),
+                           ctr=torch.zeros(1, dtype=torch.int64, device=dev))
+        return self._f
+
     def step(self, actions=None):
         N, M, dev = self.N, self.M, self.device
+        if dev.type == "cuda":
+            from mappo_amd import ops
+            f = self._fused_state()
+            f["ctr"] += 1
+            ops.synth_smac_step(f["obs"], f["share"], f["avail"], f["rew"], self.dead, f["dones"], self.p_death, self.p_term,
+                                self.seed, f["ctr"])
+            return f["obs"], f["share"], f["rew"].view(N, 1, 1).expand(N, M, 1), f["dones"], f["bad"], f["avail"]
         obs, share, avail = self._draw()
         rewards = torch.randn(N, 1, 1, device=dev).expand(N, M, 1)
         self.dead |= torch.rand(N, M, device=dev) < self.p_death

@@ -478,3 +478,12 @@ def mpe_spread_step(agent_pos, agent_vel, landmark_pos, tstep, episode, actions,
                                            _ptr(dones, torch.uint8), int(N), int(M), int(L),
                                            int(episode_length), int(seed) & (2 ** 64 - 1), _stream())
     _lib.check(rc, "mappo_mpe_spread_step")
+
+
+def synth_smac_step(obs, share_obs, avail, rewards, dead, dones, p_death, p_term, seed, counter):
+    """One step of the synthetic SMAC-shaped env (bench utility, csrc/synth_env.hip); `counter`: int64 [1] device tensor."""
+    N, M, D = obs.shape
+    rc = _lib.load().mappo_synth_smac_step(_ptr(obs), _ptr(share_obs), _ptr(avail), _ptr(rewards), _ptr(dead, torch.bool), _ptr(dones, torch.bool),
+                                           int(N), int(M), int(D), int(share_obs.shape[2]), int(avail.shape[2]), float(p_death), float(p_term),
+                                           int(seed), _ptr(counter, torch.int64), _stream())
+    _lib.check(rc, "mappo_synth_smac_step")

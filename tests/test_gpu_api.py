@@ -321,3 +321,37 @@ def test_host_env_staging_equals_device_env(gpu_device, fuse):
         for k in x:
             assert x[k] == y[k], k
     np.testing.assert_array_equal(p0, p1)
+
+
+@pytest.mark.gpu
+def test_synthetic_smac_env_fused_step():
+    """The one-launch synthetic SMAC env (bench utility): shapes, value ranges, episode structure and determinism."""
+    from mappo_amd.envs.synthetic import SyntheticSMACEnv
+    env = SyntheticSMACEnv(512, num_agents=5, obs_dim=30, share_dim=48, n_actions=9, p_death=0.05, p_term=0.1, seed=3)
+    env.reset()
+    died = term = 0
+    acc = []
+    for _ in range(20):
+        dead_before = env.dead.clone()
+        obs, share, rew, dones, bad, avail = env.step(None)
+        assert obs.shape == (512, 5, 30) and share.shape == (512, 5, 48) and avail.shape == (512, 5, 9)
+        assert rew.shape == (512, 5, 1) and dones.shape == (512, 5) and dones.dtype == torch.bool and not bad.any()
+        assert torch.isfinite(obs).all() and torch.isfinite(share).all()
+        assert (avail[:, :, 0] == 1).all() and ((avail == 0) | (avail == 1)).all()
+        assert (rew[:, 0] == rew[:, 4]).all()                               # shared reward
+        all_done = dones.all(dim=1)
+        assert (dones | ~dead_before).all()                                 # a dead agent reports done
+        assert (env.dead <= dones).all()
+        term += int((all_done & ~env.dead.any(dim=1)).sum())                # terminated envs restart alive
+        died += int((env.dead & ~dead_before).sum())
+        acc.append(torch.cat([obs.flatten(), share.flatten()]).clone())
+    x = torch.cat(acc)
+    assert abs(float(x.mean())) < 5e-3 and abs(float(x.std()) - 1.0) < 5e-3
+    assert 0.6 < float(avail[:, :, 1:].mean()) < 0.8
+    assert 0.05 * 512 * 20 < term < 0.2 * 512 * 20 and died > 0
+    env2 = SyntheticSMACEnv(512, num_agents=5, obs_dim=30, share_dim=48, n_actions=9, p_death=0.05, p_term=0.1, seed=3)
+    env2.reset()
+    o2 = None
+    for _ in range(20):
+        o2 = env2.step(None)[0]
+    assert torch.equal(o2, obs)
