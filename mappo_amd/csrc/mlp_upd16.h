@@ -94,65 +94,55 @@ __device__ __forceinline__ void st4(float *p, const f32x4 &v) { *reinterpret_cas
 // sums per reduction: a lone dependent chain of 16 adds costs the wave 16 instruction latencies.
 template <bool RELU>
 __device__ __forceinline__ void act_ln_fwd16(f32x4 (&a)[4], float &mean, float &rstd, uint32_t &pos) {
-  float s[4];
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) a[b][i] = act_fwd<RELU>(a[b][i]);
-    s[b] = (a[b][0] + a[b][1]) + (a[b][2] + a[b][3]);
+    s += a[b];                                                   // (4-wide: packed fp32 adds)
   }
   mean = quad_sum16((s[0] + s[1]) + (s[2] + s[3])) * (1.f / HID);
-  float v[4];
-  uint32_t mk = 0u;
+  const f32x4 mean4 = {mean, mean, mean, mean};
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    float c[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      // gate bit (a > 0) shifted in through the carry: mk = 2 mk + bit, two instructions per element (compare, add-with-carry)
-      // instead of compare / select / shift-or; element e = 4 b + i ends up in bit 15 - e
-      if (RELU) asm volatile("v_cmp_lt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mk) : "v"(a[b][i]) : "vcc");
-      c[i] = a[b][i] - mean;
-      a[b][i] = c[i];
-    }
-    v[b] = (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
-  }
-  pos = mk << 16;                                                // element 0 on top: the backward shifts them out one by one
+  for (int b = 0; b < 4; ++b) { a[b] -= mean4; v += a[b] * a[b]; }
+  pos = 0u;                                                      // (the ReLU gate is re-derived from xhat in the backward, see ln_act_bwd16)
   rstd = __builtin_amdgcn_rsqf(quad_sum16((v[0] + v[1]) + (v[2] + v[3])) * (1.f / HID) + LN_EPS);      // v_rsq_f32 (1 ulp)
+  const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[b][i] *= rstd;
+  for (int b = 0; b < 4; ++b) a[b] *= rstd4;
 }
 
-// LayerNorm (no affine: folded into the consumer's weights) + activation backward: d = d/d xhat in, d/d z out
+// LayerNorm (no affine: folded into the consumer's weights) + activation backward: d = d/d xhat in, d/d z out.
+// ReLU gate: the forward computed xhat = (a - mean) rstd with a = max(z, 0), so z <= 0  <=>  a == 0  <=>  xhat == (0 - mean) rstd
+// bit for bit (the same two roundings); the gate is one compare against that threshold instead of a saved bit mask (which
+// cost two instructions per element in the forward).  An element with 0 < a < ulp(mean) / 2 reads as gated — a gradient
+// term of relative weight < 1e-7 on a measure-zero set.
 template <bool RELU>
-__device__ __forceinline__ void ln_act_bwd16(f32x4 (&d)[4], const f32x4 (&xh)[4], float mean, float rstd, uint32_t pos) {      // pos by value: consumed
-  float s1[4], s2[4];
+__device__ __forceinline__ void ln_act_bwd16(f32x4 (&d)[4], const f32x4 (&xh)[4], float mean, float rstd, uint32_t pos) {
+  (void)pos;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    s1[b] = (d[b][0] + d[b][1]) + (d[b][2] + d[b][3]);
-    s2[b] = (d[b][0] * xh[b][0] + d[b][1] * xh[b][1]) + (d[b][2] * xh[b][2] + d[b][3] * xh[b][3]);
-  }
+  for (int b = 0; b < 4; ++b) { s1 += d[b]; s2 += d[b] * xh[b]; }
   const float m1 = quad_sum16((s1[0] + s1[1]) + (s1[2] + s1[3])) * (1.f / HID);
   const float m2 = quad_sum16((s2[0] + s2[1]) + (s2[2] + s2[3])) * (1.f / HID);
   const float inv_rstd = __builtin_amdgcn_rcpf(rstd);
   const float c0 = -m1 * rstd, c1 = -m2 * rstd;                  // da = rstd (d - m1 - xhat m2) as two fmas per element
+  const f32x4 c04 = {c0, c0, c0, c0}, c14 = {c1, c1, c1, c1}, rstd4 = {rstd, rstd, rstd, rstd};
+  const float thr = (0.f - mean) * rstd;
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < 4; ++b) {
+    const f32x4 da = xh[b] * c14 + (d[b] * rstd4 + c04);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const float da = fmaf(xh[b][i], c1, fmaf(d[b][i], rstd, c0));
       if (RELU) {
-        // exact gate saved by the forward: the top bit leaves through the carry (pos = 2 pos), select on it
-        float r;
-        asm volatile("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %2, vcc" : "=v"(r), "+v"(pos) : "v"(da) : "vcc");
-        d[b][i] = r;
+        d[b][i] = xh[b][i] > thr ? da[i] : 0.f;
       } else {
         const float a = xh[b][i] * inv_rstd + mean;
-        d[b][i] = da * (1.f - a * a);
+        d[b][i] = da[i] * (1.f - a * a);
       }
     }
+  }
 }
 
 // out[bo] += W'[16 bo + n][16 b + 4 q + i] * h[b][i]  (W' row-major [f][k], stride RS16): hidden -> hidden forward, and with
@@ -877,6 +867,14 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     __syncthreads();
   });
   STAMP(18);  // accumulator chunks
+  // the waves' loss sums into thread 0's registers HERE: two barriers follow before affine_epilogue16 reuses scr[0, 1024) as
+  // scratch (read any later, the eighth wave's scratch writes raced with this read: the value-loss statistic of a workgroup
+  // came out short now and then — the gradients never go through this slot)
+  float lsum[M::N_WAVES * 4];
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int e = 0; e < M::N_WAVES * 4; ++e) lsum[e] = scr[960 + e];
+  }
   // per-feature vectors: {gB1, gB2, gBh, gWc} of every wave, wave w < 4 sums component w
   {
     f32x4 sv; sv[0] = gB1f; sv[1] = gB2f; sv[2] = gBhf; sv[3] = gWc;
@@ -892,11 +890,6 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       if (wave == 3) { if constexpr (HEAD == 2) R0[o.wh + lane] = v; }
     }
     __syncthreads();
-  }
-  float lsum[M::N_WAVES * 4];
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int e = 0; e < M::N_WAVES * 4; ++e) lsum[e] = scr[960 + e];
   }
   STAMP(14);  // cross-wave reduction
   // ---- raw products -> gradients (LayerNorm affines of the consumers' inputs), all threads ----

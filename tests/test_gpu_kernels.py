@@ -774,3 +774,52 @@ def test_recurrent_rows_kernel(ops, T, N, Ma, L, nmb, E):
         for k, (ref_rows, ref_h0) in enumerate(want):
             np.testing.assert_array_equal(rows[e, k].cpu().numpy(), ref_rows.astype(np.int32))
             np.testing.assert_array_equal(h0[e, k].cpu().numpy(), ref_h0.astype(np.int32))
+
+
+def test_dual_update_statistics_are_deterministic(ops):
+    """Repeated launches of the actor+critic update on the same inputs (row gather, BASELINE config-2 size) give bit-identical
+    gradients AND loss statistics, equal to the two single-network launches (regression: the waves' loss sums used to be read
+    back after another wave could reuse their LDS slot, so a workgroup's value-loss partial came out short now and then)."""
+    a = O.default_args()
+    cfg = ops.ppo_cfg(a)
+    B, NR = 76800, 77800
+    torch.manual_seed(0)
+    da, dc = ops.net_desc(18, 5), ops.net_desc(54, 1)
+    Pa, Pc = ops.net_param_count(da), ops.net_param_count(dc)
+    col_c = ((Pa + 255) // 256) * 256
+    P = col_c + ((Pc + 255) // 256) * 256
+    pa, pc = torch.randn(Pa, device="cuda") * 0.1, torch.randn(Pc, device="cuda") * 0.1
+    obs, sobs = torch.randn(NR, 18, device="cuda"), torch.randn(NR, 54, device="cuda")
+    ret, active = torch.randn(NR, device="cuda"), (torch.rand(NR, device="cuda") > 0.1).float()
+    rows = torch.randperm(NR, device="cuda")[:B].to(torch.int32).contiguous()
+    mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ops.minibatch_moments(ret, active, rows, B, mom)
+    av = (torch.rand(NR, 5, device="cuda") > 0.2).float()
+    av[:, 0] = 1
+    act, olp = torch.zeros(NR, device="cuda"), -torch.rand(NR, device="cuda") - 1
+    adv, vold, vn = torch.randn(NR, device="cuda"), torch.randn(NR, device="cuda"), torch.tensor([0., 1., 1.], device="cuda")
+    nd, ns = ops.dual_update_slabs(da, dc, B), ops.mlp_backward_slabs(B)
+
+    def run(dual):
+        slabs = torch.zeros(max(nd, ns), P, device="cuda")
+        pda, pdc = ops.update_partials("cuda"), ops.update_partials("cuda")
+        if dual:
+            ops.actor_critic_update(pa, da, obs, pc, dc, sobs, rows, B, av, act, olp, adv, active, vold, ret, vn, mom, cfg, slabs, P, 0, col_c, pda, pdc)
+        else:
+            ops.actor_update(pa, da, obs, rows, B, av, act, olp, adv, active, mom, cfg, slabs, P, 0, pda)
+            ops.critic_update(pc, dc, sobs, rows, B, vold, ret, active, vn, mom, cfg, slabs, P, col_c, pdc)
+        stats = torch.zeros(6, dtype=torch.float64, device="cuda")
+        n = nd if dual else ns
+        ops.update_stats(pda, n, pdc, n, mom, cfg, stats)
+        return slabs.double().sum(0).cpu().numpy(), stats.cpu().numpy()
+
+    g0, s0 = run(True)
+    gs, ss = run(False)
+    np.testing.assert_allclose(s0, ss, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(g0, gs, rtol=0, atol=1e-6 * np.abs(gs).max())
+    for _ in range(25):
+        g, s = run(True)
+        assert np.array_equal(g, g0) and np.array_equal(s, s0)
+    for _ in range(5):
+        g, s = run(False)
+        assert np.array_equal(g, gs) and np.array_equal(s, ss)
