@@ -122,20 +122,31 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n_rollout_threads", type=int, default=1024, help="global under --scaling strong, per GPU under weak")
+    ap.add_argument("--config", choices=("c2", "c4"), default="c2",
+                    help="c2 = BASELINE configs[1], the configuration the metric is quoted on (default); c4 = configs[3], the SMAC MMM2 shape "
+                         "(10 agents, obs 176 / state 322 / 18 actions, GRU policy, T=400, 512 rollout threads in total, ppo_epoch 5 x 2 "
+                         "minibatches) that SURVEY 8(e) names for the strong-scaling target — no roofline / cpu_baseline objects there")
+    ap.add_argument("--n_rollout_threads", type=int, default=None, help="global under --scaling strong, per GPU under weak (default 1024; c4: 512)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong (default): n_rollout_threads is the GLOBAL count, sharded over the ranks (north_star's >= 6x at "
                          "8 GPUs is a strong-scaling target); weak: n_rollout_threads per GPU")
     ap.add_argument("--env", choices=("synthetic", "mpe"), default="synthetic",
                     help="synthetic (default, BASELINE.json: MPE-shaped N(0,1) observations) | mpe: the GPU-vectorised simple_spread "
                          "environment (mappo_amd/envs/mpe_spread.py: real dynamics, rewards and resets, still no process boundary)")
-    ap.add_argument("--episode_length", type=int, default=25)
-    ap.add_argument("--ppo_epoch", type=int, default=10)
-    ap.add_argument("--num_mini_batch", type=int, default=1)
+    ap.add_argument("--episode_length", type=int, default=None)
+    ap.add_argument("--ppo_epoch", type=int, default=None)
+    ap.add_argument("--num_mini_batch", type=int, default=None)
     ap.add_argument("--exact_minibatch_order", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_threads", type=int, default=0, help="0 = all cores of this box (max 16)")
-    return ap.parse_args()
+    ns = ap.parse_args()
+    dflt = dict(c2=(1024, 25, 10, 1), c4=(512, 400, 5, 2))[ns.config]
+    for k, v in zip(("n_rollout_threads", "episode_length", "ppo_epoch", "num_mini_batch"), dflt):
+        if getattr(ns, k) is None:
+            setattr(ns, k, v)
+    if ns.config == "c4" and ns.steps == 20 and ns.warmup == 3:
+        ns.steps, ns.warmup = 3, 2                            # an iteration is ~50 ms x 400 steps of rollout: keep the default run short
+    return ns
 
 
 def make_args(ns):
@@ -247,6 +258,68 @@ def cpu_baseline(ns, n_threads):
                 cpu_model=_cpu_model(), os_cpu_count=os.cpu_count(), runs=runs, seconds=head["seconds_per_iteration"])
 
 
+def main_c4(ns, world, rank, device, result_out, force_dp):
+    """BASELINE configs[3] (SMAC MMM2 shape, recurrent policy): same timing contract, strong or weak scaling over rollout threads."""
+    from mappo_amd.envs.synthetic import SyntheticSMACEnv
+    from mappo_amd.runner.shared.smac_runner import SMACRunner
+    from mappo_amd.distributed import DataParallel
+    from mappo_amd.config import get_config
+    M, D, S, A = 10, 176, 322, 18
+    a = get_config().parse_known_args([])[0]
+    a.algorithm_name = "rmappo"
+    a.use_recurrent_policy, a.use_naive_recurrent_policy = True, False
+    a.env_name = "StarCraft2"
+    a.episode_length, a.n_rollout_threads, a.ppo_epoch, a.num_mini_batch = ns.episode_length, ns.local_threads, ns.ppo_epoch, ns.num_mini_batch
+    a.lr = a.critic_lr = 5e-4
+    a.gain = 1.0                                               # train_smac.sh
+    a.seed = 1
+    torch.manual_seed(a.seed)
+    env = SyntheticSMACEnv(a.n_rollout_threads, M, D, S, A, seed=1 + rank, device=device)
+    dp = DataParallel() if (world > 1 or force_dp) else None
+    runner = SMACRunner(dict(all_args=a, envs=env, eval_envs=None, num_agents=M, device=device, run_dir=None, dist_group=dp))
+    runner.warmup()
+    for i in range(max(ns.warmup, 2)):
+        runner.run_episode(i, ns.warmup + ns.steps)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(ns.steps):
+        info, _ = runner.run_episode(ns.warmup + i, ns.warmup + ns.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    global_steps = a.episode_length * ns.global_threads * M
+    out = dict(metric="agent-steps/sec (collect+GAE+PPO), SMAC MMM2-shaped synthetic env, recurrent policy", value=global_steps * ns.steps / dt,
+               unit="agent-steps/s", n_gpus=world, steps=ns.steps, warmup=ns.warmup, ms_per_step=1e3 * dt / ns.steps, higher_is_better=True,
+               scaling=ns.scaling, vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="BASELINE configs[3]: SMAC MMM2 shape, 10 agents, obs 176 / state 322 / Discrete(18), "
+                                    f"n_rollout_threads={ns.global_threads} in total ({ns.scaling} scaling: {a.n_rollout_threads} on rank 0 of {world}), "
+                                    f"episode_length={a.episode_length}, GRU policy (rmappo, data_chunk_length {a.data_chunk_length}), "
+                                    f"ppo_epoch={a.ppo_epoch}, num_mini_batch={a.num_mini_batch}, lr 5e-4",
+                           n_rollout_threads_global=ns.global_threads, n_rollout_threads_rank0=a.n_rollout_threads, episode_length=a.episode_length,
+                           num_agents=M, ppo_epoch=a.ppo_epoch, num_mini_batch=a.num_mini_batch, agent_steps_per_step=global_steps,
+                           parallelism=f"dp{world}"),
+               roofline=None, cpu_baseline=None,
+               note="secondary configuration (SURVEY 8e strong-scaling shape); the roofline / cpu_baseline objects belong to the default --config c2 line",
+               last_train_info={k: float(v) for k, v in info.items()})
+    if rank == 0:
+        print(json.dumps(out), file=result_out, flush=True)
+    if world > 1 or force_dp:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ns = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -280,6 +353,8 @@ def main():
     from mappo_amd.runner.shared.mpe_runner import MPERunner
     from mappo_amd.distributed import DataParallel
 
+    if ns.config == "c4":
+        return main_c4(ns, world, rank, device, result_out, force_dp)
     args = make_args(ns)
     M, D, A = 3, 18, 5
     torch.manual_seed(args.seed)                           # identical initial replicas on every rank
