@@ -1295,6 +1295,8 @@ int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st);
 int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
                           const Wide16Args &w, const FwdArgs &a, const char *who);
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st);
+int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa,
+                                const FwdArgs &a, const Wide16Args &wc, const FwdArgs &c, int nA);
 
 #ifdef MLP_TU_WIDE
 template <int NCH>
@@ -1346,6 +1348,30 @@ int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, di
   if (ln == 0) return relu ? wide16_forward_mode<true, 0>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 0>(mode, small, grid, block, lds_bytes, st, w, a, who);
   if (ln == 1) return relu ? wide16_forward_mode<true, 1>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 1>(mode, small, grid, block, lds_bytes, st, w, a, who);
   return relu ? wide16_forward_mode<true, 2>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 2>(mode, small, grid, block, lds_bytes, st, w, a, who);
+}
+
+template <bool R, int L, int NWV>
+static int wide16_features_dual_one(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const WideDualArgs &d) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_dual_kernel<R, L, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_MLP_FWD, (wide_features16_dual_kernel<R, L, NWV>), grid, block, lds_bytes, st, d);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+static int wide16_features_dual_nw(bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const WideDualArgs &d) {
+  return small ? wide16_features_dual_one<R, L, 4>(grid, block, lds_bytes, st, d) : wide16_features_dual_one<R, L, 8>(grid, block, lds_bytes, st, d);
+}
+int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa,
+                                const FwdArgs &a, const Wide16Args &wc, const FwdArgs &c, int nA) {
+  WideDualArgs d;
+  d.wa = wa; d.wc = wc; d.a = a; d.c = c; d.nA = nA;
+  if (ln == 0) return relu ? wide16_features_dual_nw<true, 0>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 0>(small, grid, block, lds_bytes, st, d);
+  if (ln == 1) return relu ? wide16_features_dual_nw<true, 1>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 1>(small, grid, block, lds_bytes, st, d);
+  return relu ? wide16_features_dual_nw<true, 2>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 2>(small, grid, block, lds_bytes, st, d);
 }
 
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st) {
@@ -1509,6 +1535,25 @@ template int upd16x_inst<MLP_UPD_RELU, MLP_UPD_LN>(int, dim3, dim3, size_t, hipS
 #endif
 
 #if defined(MLP_TU_MAIN) || defined(MLP_TU_STEP)
+// LDS map, layer-1 arguments and launch shape of the one-launch wide forward (mlp_wide16.h) for the network in `a` (a.off / a.map set)
+static int wide_forward_prepare(FwdArgs &a, Wide16Args &w, size_t &lb, dim3 &grid, dim3 &block, bool &small, const char *who) {
+  a.map.wave_stride = 16 * TP;                                   // the tail only needs the [16][TP] logits tile of a wave
+  a.map.total = a.map.tiles + 8 * a.map.wave_stride;
+  lb = (size_t)a.map.total * sizeof(float);
+  MAPPO_REQUIRE(lb + sizeof(float) * (2 * HID * RS16 + HID) <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lb);
+  w = Wide16Args{};
+  w.params = a.params; w.x = a.x; w.rows = a.rows; w.B = a.B; w.D = a.desc.in_dim; w.w1 = a.off.w1; w.b1 = a.off.b1;
+  w.fn_w = a.desc.use_feature_norm ? a.off.fn_w : -1; w.fn_b = a.desc.use_feature_norm ? a.off.fn_b : -1;
+  // rollout-sized batches: 4-wave workgroups (twice the workgroups, one wave per SIMD) until 8-wave groups fill the chip
+  const int64_t n_tiles16 = (a.B + 15) / 16;
+  small = n_tiles16 < 8 * (int64_t)NUM_CU;
+  const int64_t n_groups = small ? (n_tiles16 + 3) / 4 : (n_tiles16 + 7) / 8;
+  const int64_t cap = small ? 2 * NUM_CU : NUM_CU;
+  grid = dim3((unsigned)(n_groups < cap ? n_groups : cap));
+  block = dim3(small ? 256 : 512);
+  return MAPPO_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1593,11 +1638,29 @@ extern "C" int mappo_mlp_features_dual(const float *params_a, const mappo_net_de
                                        int64_t B, mappo_stream_t stream) {
   if (int rc = check_desc_trunk(desc_a, "mlp_features_dual")) return rc;
   if (int rc = check_desc_trunk(desc_c, "mlp_features_dual")) return rc;
-  MAPPO_REQUIRE(desc_a->in_dim <= MAXD && desc_c->in_dim <= MAXD, "mlp_features_dual: in_dim > %d goes through mlp_features", MAXD);
+  MAPPO_REQUIRE((desc_a->in_dim <= MAXD) == (desc_c->in_dim <= MAXD) && desc_a->in_dim <= 512 && desc_c->in_dim <= 512,
+                "mlp_features_dual: both networks narrow (in_dim <= %d) or both wide (<= 512)", MAXD);
   MAPPO_REQUIRE(desc_a->layer_N == desc_c->layer_N && desc_a->use_relu == desc_c->use_relu,
                 "mlp_features_dual: the networks must share layer_N and the activation");
   MAPPO_REQUIRE(params_a && x_a && featT_a && params_c && x_c && featT_c && B > 0, "mlp_features_dual: bad arguments");
   MAPPO_CLEAR_STICKY();
+  if (desc_a->in_dim > MAXD) {
+    // wide inputs: the one-launch wide forward (mlp_wide16.h) of both networks by workgroup role
+    FwdArgs a = {}, c = {};
+    a.params = params_a; a.x = x_a; a.out = featT_a; a.desc = *desc_a; a.B = B; a.off = net_offsets(a.desc); a.map = lds_map(a.desc, 8);
+    c.params = params_c; c.x = x_c; c.out = featT_c; c.desc = *desc_c; c.B = B; c.off = net_offsets(c.desc); c.map = lds_map(c.desc, 8);
+    Wide16Args wa, wc;
+    size_t lba, lbc;
+    dim3 ga, gc, ba, bc;
+    bool sa, sc;
+    if (int rcp = wide_forward_prepare(a, wa, lba, ga, ba, sa, "mlp_features_dual")) return rcp;
+    if (int rcp = wide_forward_prepare(c, wc, lbc, gc, bc, sc, "mlp_features_dual")) return rcp;
+    if (int rcw = wide16_launch_features_dual(desc_a->use_relu != 0, desc_a->layer_N, sa, dim3(ga.x + gc.x), ba, lba > lbc ? lba : lbc,
+                                              as_stream(stream), wa, a, wc, c, (int)ga.x))
+      return rcw;
+    MAPPO_CHECK_LAUNCH("mlp_features_dual");
+    return MAPPO_OK;
+  }
   const int64_t n_tiles = (B + 15) / 16;
   const int want = n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1);
   int nw = fit_waves(*desc_a, want);
@@ -1718,19 +1781,11 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
     const char *e16 = getenv("MAPPO_UPD16");
     if (a.desc.in_dim > MAXD && a.desc.in_dim <= 512 && a.x_M == 0 && !(e16 && e16[0] == '0')) {
       // wide inputs: layer 1 from registers + double-buffered W1 chunks, the rest of the network on the same tile (mlp_wide16.h)
-      a.map.wave_stride = 16 * TP;                               // the tail only needs the [16][TP] logits tile of a wave
-      a.map.total = a.map.tiles + 8 * a.map.wave_stride;
-      const size_t lb = (size_t)a.map.total * sizeof(float);
-      MAPPO_REQUIRE(lb + sizeof(float) * (2 * HID * RS16 + HID) <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lb);
-      Wide16Args w = {};
-      w.params = a.params; w.x = a.x; w.rows = a.rows; w.B = a.B; w.D = a.desc.in_dim; w.w1 = a.off.w1; w.b1 = a.off.b1;
-      w.fn_w = a.desc.use_feature_norm ? a.off.fn_w : -1; w.fn_b = a.desc.use_feature_norm ? a.off.fn_b : -1;
-      // rollout-sized batches: 4-wave workgroups (twice the workgroups, one wave per SIMD) until 8-wave groups fill the chip
-      const int64_t n_tiles16 = (a.B + 15) / 16;
-      const bool small = n_tiles16 < 8 * (int64_t)NUM_CU;
-      const int64_t n_groups = small ? (n_tiles16 + 3) / 4 : (n_tiles16 + 7) / 8;
-      const int64_t cap = small ? 2 * NUM_CU : NUM_CU;
-      dim3 g2((unsigned)(n_groups < cap ? n_groups : cap)), b2(small ? 256 : 512);
+      Wide16Args w;
+      size_t lb;
+      dim3 g2, b2;
+      bool small;
+      if (int rcp = wide_forward_prepare(a, w, lb, g2, b2, small, who)) return rcp;
       if (int rcw = wide16_launch_forward(MODE, a.desc.use_relu != 0, LN, small, g2, b2, lb, st, w, a, who)) return rcw;
       MAPPO_CHECK_LAUNCH(who);
       return MAPPO_OK;

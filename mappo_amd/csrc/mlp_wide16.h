@@ -91,7 +91,8 @@ __device__ __forceinline__ f32x4 ld4u(const float *ptr) {             // 16-byte
 //   * Per-element work is kept off the main path as in the training kernel below: 1/std on the 16 accumulators, packed
 //     statistics, row-end clamping / masking only for the last chunk.
 template <int NCH, int NW, class Pre, class Tail>
-__device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[HID * RS16], float *sB, Pre &&pre, Tail &&tail) {
+__device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[HID * RS16], float *sB, const int bid, const int nb,
+                                              Pre &&pre, Tail &&tail) {      // workgroup `bid` of the `nb` that share this network
   constexpr int TPR = NW, CW = 64 / NW, CV = CW / 4;          // threads per weight row, floats (vectors) per thread and chunk
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -168,7 +169,7 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
     }
   };
 
-  int64_t grp = blockIdx.x;
+  int64_t grp = bid;
   const bool any = grp < n_groups;                            // (uniform; the launch never has more workgroups than groups)
   if (any) {
     const float *xr = row_ptr(grp);
@@ -187,7 +188,7 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
   for (;;) {
     const int64_t i = (grp * NW + wave) * 16 + n;
     const bool ok = i < p.B;
-    const int64_t next = grp + gridDim.x;
+    const int64_t next = grp + nb;
     const bool has_next = next < n_groups;
     const float *xr_next = row_ptr(has_next ? next : grp);
     int ql = q;
@@ -412,18 +413,36 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
 // The whole forward of a wide-input network in one launch (rollout: get_actions / get_values / trunk features): layer 1 as above,
 // then the register-resident 16x16x4 tail of the narrow kernels (mlp_fwd16.h) on the same tile.
 template <bool RELU, int LN, int MODE, int NW, int NCH>
-__global__ __launch_bounds__(64 * NW, 2) void wide_forward16_kernel(Wide16Args w, FwdArgs p) {
-  extern __shared__ __align__(16) float lds[];
-  __shared__ __align__(16) float sW[2][HID * RS16];
-  __shared__ __align__(16) float sB[HID];
+__device__ __forceinline__ void wide_forward16_body(const Wide16Args &w, const FwdArgs &p, float *lds, float (*sW)[HID * RS16], float *sB,
+                                                    const int bid, const int nb) {
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float *tZ = lds + p.map.tiles + wave * p.map.wave_stride;
-  wide16_layer1<NCH, NW>(w, sW, sB,
+  wide16_layer1<NCH, NW>(w, sW, sB, bid, nb,
     [&]() __attribute__((always_inline)) { stage_all_weights<LN>(lds, p.map, p.params, p.off, p.desc); },    // everything but W1 (streamed in chunks)
     [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
       forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, j, q, tZ);
     });
+}
+
+template <bool RELU, int LN, int MODE, int NW, int NCH>
+__global__ __launch_bounds__(64 * NW, 2) void wide_forward16_kernel(Wide16Args w, FwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ __align__(16) float sW[2][HID * RS16];
+  __shared__ __align__(16) float sB[HID];
+  wide_forward16_body<RELU, LN, MODE, NW, NCH>(w, p, lds, sW, sB, blockIdx.x, gridDim.x);
+}
+
+// Trunk features of a recurrent actor AND critic with wide inputs in one launch (rollout step: the two networks read different
+// rows of the same step; at 40 tiles each neither fills the chip): workgroups [0, nA) actor, [nA, gridDim.x) critic.
+struct WideDualArgs { Wide16Args wa, wc; FwdArgs a, c; int nA; };
+template <bool RELU, int LN, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void wide_features16_dual_kernel(WideDualArgs d) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ __align__(16) float sW[2][HID * RS16];
+  __shared__ __align__(16) float sB[HID];
+  if ((int)blockIdx.x < d.nA) wide_forward16_body<RELU, LN, 2, NW, 8>(d.wa, d.a, lds, sW, sB, blockIdx.x, d.nA);
+  else wide_forward16_body<RELU, LN, 2, NW, 8>(d.wc, d.c, lds, sW, sB, (int)blockIdx.x - d.nA, (int)gridDim.x - d.nA);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------

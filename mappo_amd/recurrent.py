@@ -65,9 +65,11 @@ def actor_step(actor, obs, rnn_states, masks, avail, deterministic, actions_f, l
 
 
 def can_step_dual(actor, critic):
-    """Both networks recurrent with narrow inputs and the same trunk shape: their rollout step runs as two dual launches."""
+    """Both networks recurrent with inputs of the same class (<= 64 wide, or 65..512) and the same trunk shape: their rollout
+    step runs as two dual launches."""
     da, dc = actor.desc, critic.desc
-    return (da.recurrent and dc.recurrent and da.in_dim <= 64 and dc.in_dim <= 64 and da.layer_N == dc.layer_N
+    same_class = (da.in_dim <= 64) == (dc.in_dim <= 64) and max(da.in_dim, dc.in_dim) <= 512      # both narrow or both wide
+    return (da.recurrent and dc.recurrent and same_class and da.layer_N == dc.layer_N
             and da.use_relu == dc.use_relu and actor._recurrent_N == 1 and critic._recurrent_N == 1)
 
 

@@ -398,17 +398,19 @@ def test_gru_backward_with_dx_matches_deferred_input_backward(M):
             np.testing.assert_array_equal(y, x)                             # with / without dxT: identical
 
 
-def test_recurrent_step_dual_matches_separate_kernels(M):
+@pytest.mark.parametrize("Do,Ds,A,R", [(30, 48, 9, 3 * 37 + 5), (176, 322, 18, 640), (130, 70, 5, 37)])
+def test_recurrent_step_dual_matches_separate_kernels(M, Do, Ds, A, R):
     """mappo_mlp_features_dual + mappo_gru_step_dual (both networks per launch) == the per-network launches
-    (mappo_mlp_features + mappo_gru_forward head modes 2 / 1), bit for bit: actions, log-probs, values, next states."""
+    (mappo_mlp_features + mappo_gru_forward head modes 2 / 1), bit for bit: actions, log-probs, values, next states.
+    Narrow inputs (SMAC 3m shapes) and wide ones (MMM2 shapes; widths that are not multiples of 4)."""
     from mappo_amd import recurrent
     a = make_args(M, use_recurrent_policy=True, algorithm_name="rmappo")
-    pol = M.R_MAPPOPolicy(a, [30], [48], M.Discrete(9))
+    pol = M.R_MAPPOPolicy(a, [Do], [Ds], M.Discrete(A))
     assert recurrent.can_step_dual(pol.actor, pol.critic)
-    R, H, A = 3 * 37 + 5, 64, 9
+    H = 64
     g = torch.Generator(device="cuda").manual_seed(4)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
-    obs, cent, ha, hc = rnd(R, 30), rnd(R, 48), rnd(R, 1, H), rnd(R, 1, H)
+    obs, cent, ha, hc = rnd(R, Do), rnd(R, Ds), rnd(R, 1, H), rnd(R, 1, H)
     masks = (torch.rand(R, 1, device="cuda", generator=g) > 0.3).float()
     avail = (torch.rand(R, A, device="cuda", generator=g) < 0.7).float()
     avail[:, 0] = 1.0
