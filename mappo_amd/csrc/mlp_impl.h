@@ -1492,6 +1492,7 @@ static int upd16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
 template <bool R, int L>
 int upd16_inst(int head, bool wide, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
   if (head == 1) return wide ? upd16_launch<R, L, 1, true>(grid, block, lds_bytes, st, a) : upd16_launch<R, L, 1, false>(grid, block, lds_bytes, st, a);
+  if (head == 3) return wide ? upd16_launch<R, L, 3, true>(grid, block, lds_bytes, st, a) : upd16_launch<R, L, 3, false>(grid, block, lds_bytes, st, a);
   return wide ? upd16_launch<R, L, 2, true>(grid, block, lds_bytes, st, a) : upd16_launch<R, L, 2, false>(grid, block, lds_bytes, st, a);
 }
 template int upd16_inst<MLP_UPD_RELU, MLP_UPD_LN>(int, bool, dim3, dim3, size_t, hipStream_t, const Upd16Args &);
@@ -1529,6 +1530,7 @@ static int upd16x_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st
 }
 template <bool R, int L>
 int upd16x_inst(int head, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
+  if (head == 3) return upd16x_launch<R, L, 3>(grid, block, lds_bytes, st, a);
   return head == 1 ? upd16x_launch<R, L, 1>(grid, block, lds_bytes, st, a) : upd16x_launch<R, L, 2>(grid, block, lds_bytes, st, a);
 }
 template int upd16x_inst<MLP_UPD_RELU, MLP_UPD_LN>(int, dim3, dim3, size_t, hipStream_t, const Upd16Args &);
@@ -1862,6 +1864,18 @@ static int upd16_tile_cost(const mappo_net_desc &d, bool actor) {
   if (actor) c += 16 + 16 + 4 * ((d.out_dim + 3) >> 2);
   return c;
 }
+// trunk backward (gradient arriving at the trunk output; recurrent networks): same kernels, no head
+static bool upd16_trunk_eligible(const mappo_net_desc &d) {
+  const char *e = getenv("MAPPO_UPD16");
+  if (e && e[0] == '0') return false;
+  return d.in_dim <= 512 && d.layer_N <= 1;
+}
+static size_t upd16_trunk_lds_floats(const mappo_net_desc &d) {
+  if (d.in_dim > MAXD) return d.layer_N > 0 ? L16<1, 3, true, true>::TOTAL : L16<0, 3, true, true>::TOTAL;
+  const bool w = d.in_dim > 32;
+  if (d.layer_N > 0) return w ? L16<1, 3, true>::TOTAL : L16<1, 3, false>::TOTAL;
+  return w ? L16<0, 3, true>::TOTAL : L16<0, 3, false>::TOTAL;
+}
 static size_t upd16_lds_floats(const mappo_net_desc &d, bool actor) {
   const bool w = d.in_dim > 32;
   if (actor) {
@@ -1966,17 +1980,22 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
   a.stamps = g_stamp_host;
 #endif
   int rc;
-  if ((HEAD == 1 || HEAD == 2) && upd16_eligible(d, HEAD == 1)) {
+  const bool trunk16 = HEAD == 3 && upd16_trunk_eligible(d);
+  if (((HEAD == 1 || HEAD == 2) && upd16_eligible(d, HEAD == 1)) || (trunk16 && d.in_dim <= MAXD)) {
     // one wave per 16-sample tile (mlp_upd16.h)
     Upd16Args a16 = {};
     a16.u = a;
-    if (int rc16 = prep16(a16, HEAD == 1, who)) return rc16;
-    const size_t lds_bytes = upd16_lds_floats(d, HEAD == 1) * sizeof(float);
+    if (HEAD == 3) {
+      a16.u.off = a.off;
+      a16.zero_row0 = a16.zero_row1 = 0; a16.zero_col0 = 0; a16.zero_cols = 0; a16.zero_partials = nullptr;
+      MAPPO_REQUIRE(upd16_trunk_lds_floats(d) * sizeof(float) <= UPD16_LDS_MAX, "%s: needs %zu B of LDS", who, upd16_trunk_lds_floats(d) * sizeof(float));
+    } else if (int rc16 = prep16(a16, HEAD == 1, who)) return rc16;
+    const size_t lds_bytes = (HEAD == 3 ? upd16_trunk_lds_floats(d) : upd16_lds_floats(d, HEAD == 1)) * sizeof(float);
     dim3 grid((unsigned)nb), block(WAVE * UPD16_WAVES);
     const bool wide = d.in_dim > 32;
     if (LN == 0) rc = relu ? upd16_inst<true, 0>(HEAD, wide, grid, block, lds_bytes, st, a16) : upd16_inst<false, 0>(HEAD, wide, grid, block, lds_bytes, st, a16);
     else rc = relu ? upd16_inst<true, 1>(HEAD, wide, grid, block, lds_bytes, st, a16) : upd16_inst<false, 1>(HEAD, wide, grid, block, lds_bytes, st, a16);
-  } else if ((HEAD == 1 || HEAD == 2) && upd16x_eligible(d, HEAD == 1)) {
+  } else if (((HEAD == 1 || HEAD == 2) && upd16x_eligible(d, HEAD == 1)) || (trunk16 && d.in_dim > MAXD)) {
     // wide inputs: layer-1 forward as its own kernel (mlp_wide16.h), then the 16-sample-tile update kernel from z1 on; the
     // caller's mappo_wide_l1_backward turns dz1 + the row statistics into the W1 / feature-norm gradients
     MAPPO_REQUIRE(a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
@@ -1986,8 +2005,11 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
     wide_layout_set(a.wide_ws, 1);
     Upd16Args a16 = {};
     a16.u = a;
-    if (int rc16 = prep16x(a16, HEAD == 1, who)) return rc16;
-    const size_t lds_bytes = upd16x_lds_floats(d, HEAD == 1) * sizeof(float);
+    if (HEAD == 3) {
+      a16.zero_row0 = a16.zero_row1 = 0; a16.zero_col0 = 0; a16.zero_cols = 0; a16.zero_partials = nullptr;
+      MAPPO_REQUIRE(upd16_trunk_lds_floats(d) * sizeof(float) <= UPD16_LDS_MAX, "%s: needs %zu B of LDS", who, upd16_trunk_lds_floats(d) * sizeof(float));
+    } else if (int rc16 = prep16x(a16, HEAD == 1, who)) return rc16;
+    const size_t lds_bytes = (HEAD == 3 ? upd16_trunk_lds_floats(d) : upd16x_lds_floats(d, HEAD == 1)) * sizeof(float);
     dim3 grid((unsigned)nb), block(WAVE * UPD16_WAVES);
     if (LN == 0) rc = relu ? upd16x_inst<true, 0>(HEAD, grid, block, lds_bytes, st, a16) : upd16x_inst<false, 0>(HEAD, grid, block, lds_bytes, st, a16);
     else rc = relu ? upd16x_inst<true, 1>(HEAD, grid, block, lds_bytes, st, a16) : upd16x_inst<false, 1>(HEAD, grid, block, lds_bytes, st, a16);

@@ -403,7 +403,7 @@ __device__ __forceinline__ void affine_epilogue16(float *R, int wo, int bo, int 
 // Workgroup `bid` of the `nb` workgroups that share this network's rows.  512 threads (8 waves, 2 per SIMD).
 template <bool RELU, int LN, int HEAD, bool WIDE, bool XL1 = false>
 __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, const int bid, const int nb) {
-  static_assert(LN <= 1 && (HEAD == 1 || HEAD == 2), "update16: layer_N <= 1, in-kernel loss heads only");
+  static_assert(LN <= 1 && (HEAD == 1 || HEAD == 2 || HEAD == 3), "update16: layer_N <= 1; heads: actor loss, critic loss, trunk (gradient in)");
   static_assert(!XL1 || WIDE, "XL1 uses the 16-register prefetch block");
   constexpr int NV = WIDE ? 16 : 8, NBK = WIDE ? 4 : 2;
   const UpdArgs &p = P.u;
@@ -449,7 +449,7 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
 #pragma unroll
       for (int j = 0; j < 8; ++j) whr[j] = g[o.wh + min(f8, A - 1) * HID + part + 8 * j];
       bhraw = g[o.bh + min(f8, A - 1)];
-    } else {
+    } else if constexpr (HEAD == 2) {
       whr[0] = g[o.wh + ve];
       bhraw = g[o.bh];
     }
@@ -532,7 +532,8 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   float *Udl = lds + M::TILES + wave * M::WAVE_STRIDE + M::UDL;
   const int xs = M::XST;
 
-  LossScales ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
+  LossScales ls = {};
+  if constexpr (HEAD != 3) ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
   // (wave-uniform values computed on the vector ALU: move them to scalar registers, the vector file is what is scarce here)
   ls.scale_pi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.scale_pi)));
   ls.scale_v = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.scale_v)));
@@ -546,6 +547,11 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   // bias-gradient partials: gB1/gB2[bf] = sum over this lane's samples of dz[16 bf + n] (reduced over q in the epilogue);
   // gBh: actor = the same for d logits (action n), critic = per-lane sum of dv; gWc: critic raw head product, lane = k
   float gB1[4] = {0.f, 0.f, 0.f, 0.f}, gB2[4] = {0.f, 0.f, 0.f, 0.f}, gBh[1] = {0.f}, gWc = 0.f;
+  // HEAD 3 (trunk only: the gradient arrives at the trunk output, feature-major dHT [64][B]): the last LayerNorm keeps its
+  // affine (out = gamma xhat + beta), its gradients are per-lane sums over the lane's samples (accumulator layout)
+  f32x4 gLg[HEAD == 3 ? 4 : 1], gLb[HEAD == 3 ? 4 : 1];
+#pragma unroll
+  for (int b = 0; b < (HEAD == 3 ? 4 : 1); ++b) { gLg[b] = f32x4{0.f, 0.f, 0.f, 0.f}; gLb[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -648,6 +654,15 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     // register-hungry backward pass only — but that is where the pressure peaks: 106 spilled registers, measured)
     if constexpr (XL1) prefetch16x<HEAD>(pf, p, z1, tile + tile_stride, n_tiles, A, n, q);
     else prefetch16<HEAD, WIDE>(pf, p, tile + tile_stride, n_tiles, D, C, A, lane, n, q);
+    f32x4 dh[HEAD == 3 ? 4 : 1];
+    if constexpr (HEAD == 3) {
+      // d(trunk output) of this tile: 16 dwords per lane (64-byte segments), in flight under the forward
+      const float *dcol = p.dHT + min(tile * 16 + n, p.B - 1);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+    }
     act_ln_fwd16<RELU>(xh, mean1, rstd1, pos1);
     STAMP(3);   // prefetch issue + act/LN 1
     // ---- hidden layer ----
@@ -666,7 +681,18 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     STAMP(5);   // act/LN 2
     // xh = xhat of the last LayerNorm
     f32x4 dx[4];
-    if constexpr (HEAD == 2) {
+    if constexpr (HEAD == 3) {
+      const float *gam = lds + (LN > 0 ? M::G2 : M::G1);       // raw gamma of the LayerNorm that ends the trunk
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 d = dh[b];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = live ? d[i] : 0.f;
+        gLg[b] += d * xh[b];
+        gLb[b] += d;
+        dx[b] = d * ld4(gam + 16 * b + 4 * q);
+      }
+    } else if constexpr (HEAD == 2) {
       // ---- critic head (out_dim 1) on the VALU ----
       f32x4 wv[4];
       float acc = 0.f;
@@ -775,8 +801,10 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   float ewh[NJH], ew2[LN > 0 ? 8 : 1], ew1[8];
   {
     const int k = threadIdx.x & 63, part = threadIdx.x >> 6;
+    if constexpr (HEAD != 3) {
 #pragma unroll
-    for (int j = 0; j < NJH; ++j) ewh[j] = p.params[o.wh + min(part + 8 * j, A - 1) * HID + k];
+      for (int j = 0; j < NJH; ++j) ewh[j] = p.params[o.wh + min(part + 8 * j, A - 1) * HID + k];
+    }
     if constexpr (LN > 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) ew2[j] = p.params[o.w2[0] + (part + 8 * j) * HID + k];
@@ -790,6 +818,19 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, gB1x[b]);
     wave_lds_sync();
     gB1x_f = col_sum16(Ut, RS16, lane);                         // lane = feature
+    wave_lds_sync();
+  }
+  float gLg_f = 0.f, gLb_f = 0.f;
+  if constexpr (HEAD == 3) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, gLg[b]);
+    wave_lds_sync();
+    gLg_f = col_sum16(Ut, RS16, lane);                          // lane = feature
+    wave_lds_sync();
+#pragma unroll
+    for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, gLb[b]);
+    wave_lds_sync();
+    gLb_f = col_sum16(Ut, RS16, lane);
     wave_lds_sync();
   }
   __syncthreads();                                              // every wave is done with its tiles: the tile area is free
@@ -808,17 +849,18 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     for (int bf = 0; bf < 4; ++bf) { t1[bf] = quad_sum16(gB1[bf]); t2[bf] = LN > 0 ? quad_sum16(gB2[bf]) : 0.f; }
     gB1f = XL1 ? gB1x_f : (q == 0 ? t1[0] : (q == 1 ? t1[1] : (q == 2 ? t1[2] : t1[3])));
     gB2f = q == 0 ? t2[0] : (q == 1 ? t2[1] : (q == 2 ? t2[2] : t2[3]));
-    gBhf = HEAD == 1 ? quad_sum16(gBh[0]) : wave_sum_f(gBh[0]);   // actor: lane n < 16 = action | critic: sum of dv in lane 0
+    gBhf = HEAD == 1 ? quad_sum16(gBh[0]) : (HEAD == 2 ? wave_sum_f(gBh[0]) : gLg_f);   // actor: lane n < 16 = action | critic: sum of dv in lane 0 | trunk: d gamma
+    if constexpr (HEAD == 3) gWc = gLb_f;                         // trunk: d beta rides in the critic's head-product slot
   }
   double pold[4] = {0.0, 0.0, 0.0, 0.0};
-  if (threadIdx.x == 0 && p.cfg.accumulate_partials) {
+  if (HEAD != 3 && threadIdx.x == 0 && p.cfg.accumulate_partials) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) pold[k] = p.partials[(size_t)bid * 4 + k];      // in flight under the reduction
   }
   // ---- sum the waves' raw products (deterministic: fixed order, no atomics).  The accumulators (f32x4 per lane) go through
   // a [wave][CH][lane] buffer CH at a time, one 16-byte store each; wave w then sums accumulator 8 c + w of chunk c over the
   // 8 source waves (16-byte reads) and scatters the four sums to the flat parameter layout in R0.
-  const int Pn = o.total;
+  const int Pn = HEAD == 3 ? (o.gru_wih >= 0 ? o.gru_wih : o.wh) : o.total;      // trunk only: the parameters in front of the GRU / head
   constexpr int CH = M::CH;                                     // accumulators per chunk (8 | 4)
   float *cb = scr + 1024;                                       // chunk buffer: n_waves x CH x 256 floats
   const int rb = XL1 ? o.b1 : 0;                                // XL1: W1 / feature-norm gradients are not this kernel's
@@ -886,8 +928,14 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       for (int sw = 0; sw < UPD16_THREADS / WAVE; ++sw) v += cb[(sw * 64 + lane) * 4 + wave];
       if (wave == 0) R0[o.b1 + lane] = v;
       if (wave == 1) { if constexpr (LN > 0) R0[o.b2[0] + lane] = v; }
-      if (wave == 2) { if (HEAD == 1 ? lane < A : lane == 0) R0[o.bh + lane] = v; }
-      if (wave == 3) { if constexpr (HEAD == 2) R0[o.wh + lane] = v; }
+      if (wave == 2) {
+        if constexpr (HEAD == 3) R0[(LN > 0 ? o.ln2_w[0] : o.ln1_w) + lane] = v;
+        else if (HEAD == 1 ? lane < A : lane == 0) R0[o.bh + lane] = v;
+      }
+      if (wave == 3) {
+        if constexpr (HEAD == 2) R0[o.wh + lane] = v;
+        if constexpr (HEAD == 3) R0[(LN > 0 ? o.ln2_b[0] : o.ln1_b) + lane] = v;
+      }
     }
     __syncthreads();
   }
@@ -896,14 +944,14 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   {
     const int gl = LN > 0 ? M::G2 : M::G1, tl = LN > 0 ? M::T2 : M::T1;
     const int ogl = LN > 0 ? o.ln2_w[0] : o.ln1_w, otl = LN > 0 ? o.ln2_b[0] : o.ln1_b;
-    affine_epilogue16<NJH>(R0, o.wh, o.bh, A, HID, lds + gl, lds + tl, ewh, ogl, otl, scr);
+    if constexpr (HEAD != 3) affine_epilogue16<NJH>(R0, o.wh, o.bh, A, HID, lds + gl, lds + tl, ewh, ogl, otl, scr);
     if constexpr (LN > 0) affine_epilogue16<8>(R0, o.w2[0], o.b2[0], HID, HID, lds + M::G1, lds + M::T1, ew2, o.ln1_w, o.ln1_b, scr);
     if (fnorm && !XL1) affine_epilogue16<8>(R0, o.w1, o.b1, HID, D, lds + M::FN_W, lds + M::FN_B, ew1, o.fn_w, o.fn_b, scr);
   }
   STAMP(15);  // raw -> gradient transform
   float *slab = p.slabs + (size_t)bid * p.slab_stride + p.slab_col0;
   for (int e = rb + threadIdx.x; e < Pn; e += blockDim.x) slab[e] = R0[e];
-  if (threadIdx.x == 0) {
+  if (HEAD != 3 && threadIdx.x == 0) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double v = pold[k];
