@@ -548,10 +548,8 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   // gBh: actor = the same for d logits (action n), critic = per-lane sum of dv; gWc: critic raw head product, lane = k
   float gB1[4] = {0.f, 0.f, 0.f, 0.f}, gB2[4] = {0.f, 0.f, 0.f, 0.f}, gBh[1] = {0.f}, gWc = 0.f;
   // HEAD 3 (trunk only: the gradient arrives at the trunk output, feature-major dHT [64][B]): the last LayerNorm keeps its
-  // affine (out = gamma xhat + beta), its gradients are per-lane sums over the lane's samples (accumulator layout)
-  f32x4 gLg[HEAD == 3 ? 4 : 1], gLb[HEAD == 3 ? 4 : 1];
-#pragma unroll
-  for (int b = 0; b < (HEAD == 3 ? 4 : 1); ++b) { gLg[b] = f32x4{0.f, 0.f, 0.f, 0.f}; gLb[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  // affine (out = gamma xhat + beta), its gradients are column sums of the tile's dH o xhat and dH
+  float gLg_f = 0.f, gLb_f = 0.f;                                // lane = feature (column sums of the wave's scratch tile, like gWc)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
 #pragma unroll
@@ -576,6 +574,17 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   const float *rawp = Ux + n * D + q * C;                       // flat commit: own features inside the linear [16][D] block
   float *x0p = Ux + n * xs + q * NV;                            // xhat0 [sample][q NV + t]: chunk-major columns (see the epilogue)
 
+  // (with 128 weight-gradient accumulators — inputs 33..64 wide — there is no room for a second set: the loads then go out at
+  // the top of their own tile)
+  constexpr bool DH_AHEAD = HEAD == 3 && (XL1 || !WIDE);
+  f32x4 dh_next[DH_AHEAD ? 4 : 1];
+  if constexpr (DH_AHEAD) {
+    const float *dcol = p.dHT + min(tile0 * 16 + n, p.B - 1);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dh_next[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+  }
   for (int64_t tile = tile0; tile < n_tiles; tile += tile_stride) {
     const int n_valid = pf.n_valid;
     const bool live = n < n_valid;
@@ -656,12 +665,23 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     else prefetch16<HEAD, WIDE>(pf, p, tile + tile_stride, n_tiles, D, C, A, lane, n, q);
     f32x4 dh[HEAD == 3 ? 4 : 1];
     if constexpr (HEAD == 3) {
-      // d(trunk output) of this tile: 16 dwords per lane (64-byte segments), in flight under the forward
-      const float *dcol = p.dHT + min(tile * 16 + n, p.B - 1);
+      // d(trunk output): this tile's values were fetched a tile ago; the next tile's 16 dwords per lane (64-byte segments)
+      // go out now, with the next tile's rows
+      if constexpr (DH_AHEAD) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < 4; ++b) dh[b] = dh_next[b];
+        const float *dcol = p.dHT + min((tile + tile_stride) * 16 + n, p.B - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) dh[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dh_next[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+      } else {
+        const float *dcol = p.dHT + min(tile * 16 + n, p.B - 1);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dh[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+      }
     }
     act_ln_fwd16<RELU>(xh, mean1, rstd1, pos1);
     STAMP(3);   // prefetch issue + act/LN 1
@@ -685,13 +705,20 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       const float *gam = lds + (LN > 0 ? M::G2 : M::G1);       // raw gamma of the LayerNorm that ends the trunk
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        f32x4 d = dh[b];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = live ? d[i] : 0.f;
-        gLg[b] += d * xh[b];
-        gLb[b] += d;
-        dx[b] = d * ld4(gam + 16 * b + 4 * q);
+        for (int i = 0; i < 4; ++i) dh[b][i] = live ? dh[b][i] : 0.f;
+        st4(Ut + n * RS16 + 16 * b + 4 * q, dh[b] * xh[b]);
       }
+      wave_lds_sync();
+      gLg_f += col_sum16(Ut, RS16, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, dh[b]);
+      wave_lds_sync();
+      gLb_f += col_sum16(Ut, RS16, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int b = 0; b < 4; ++b) dx[b] = dh[b] * ld4(gam + 16 * b + 4 * q);
     } else if constexpr (HEAD == 2) {
       // ---- critic head (out_dim 1) on the VALU ----
       f32x4 wv[4];
@@ -818,19 +845,6 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, gB1x[b]);
     wave_lds_sync();
     gB1x_f = col_sum16(Ut, RS16, lane);                         // lane = feature
-    wave_lds_sync();
-  }
-  float gLg_f = 0.f, gLb_f = 0.f;
-  if constexpr (HEAD == 3) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, gLg[b]);
-    wave_lds_sync();
-    gLg_f = col_sum16(Ut, RS16, lane);                          // lane = feature
-    wave_lds_sync();
-#pragma unroll
-    for (int b = 0; b < 4; ++b) st4(Ut + n * RS16 + 16 * b + 4 * q, gLb[b]);
-    wave_lds_sync();
-    gLb_f = col_sum16(Ut, RS16, lane);
     wave_lds_sync();
   }
   __syncthreads();                                              // every wave is done with its tiles: the tile area is free
