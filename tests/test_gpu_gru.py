@@ -491,3 +491,52 @@ def test_smac_runner_eval_loop(M):
     rate = runner.eval(0)
     assert eval_env.ended >= 7 and eval_env.picked_ok
     assert rate == eval_env.won / eval_env.ended
+
+
+def test_config3_full_size_train_vs_oracle_on_active_subset(M):
+    """BASELINE configs[2] at FULL size (T=400, N=256 rollout threads, 3 agents, obs 30 / state 48 / 9 actions, GRU, chunks of 10:
+    307 200 rows, 30 720 chunks per update).  The oracle cannot run that on the CPU in test time, so the buffer is built with
+    active_masks == 0 everywhere except four rollout threads: with the active-mask denominators (r_mappo.py:84,130-134; the
+    nan-masked advantage statistics :174-182) and ValueNorm off, inactive rows contribute exactly nothing, and R_MAPPO.train on
+    the full buffer must equal the oracle's train on the 4-thread sub-buffer — losses, entropy, gradient norms, updated weights
+    (`ratio` is an unmasked mean: not compared).  Every chunk still runs through the full-size kernels."""
+    T, N, Ma, D, S, A, L = 400, 256, 3, 30, 48, 9, 10
+    keep = [5, 77, 130, 201]
+    common = dict(episode_length=T, lr=5e-4, critic_lr=5e-4, ppo_epoch=2, num_mini_batch=1, use_recurrent_policy=True,
+                  data_chunk_length=L, use_valuenorm=False)
+    a = make_args(M, n_rollout_threads=N, perm_device="cpu", algorithm_name="rmappo", **common)
+    torch.manual_seed(13)
+    pol = M.R_MAPPOPolicy(a, [D], [S], M.Discrete(A))
+    tr = M.R_MAPPO(a, pol)
+    buf = M.SharedReplayBuffer(a, Ma, [D], [S], M.Discrete(A))
+    g = torch.Generator(device="cuda").manual_seed(17)
+    rnd = lambda shape: torch.randn(tuple(shape), device="cuda", generator=g)
+    for n in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "rewards"):
+        getattr(buf, n).copy_(rnd(getattr(buf, n).shape))
+    buf.value_preds.copy_(rnd(buf.value_preds.shape) * 0.3)
+    buf.returns.copy_(rnd(buf.returns.shape) * 2)
+    buf.actions.copy_(torch.randint(0, A, tuple(buf.actions.shape), device="cuda", generator=g).float())
+    buf.action_log_probs.copy_(-rnd(buf.actions.shape).abs() - 1)
+    buf.masks.copy_((torch.rand(tuple(buf.masks.shape), device="cuda", generator=g) > 0.05).float())
+    buf.available_actions.fill_(1.0)                            # (all actions available: the stored actions were drawn uniformly)
+    act = torch.zeros(tuple(buf.active_masks.shape), device="cuda")
+    act[:, keep] = (torch.rand(act[:, keep].shape, device="cuda", generator=g) > 0.2).float()
+    buf.active_masks.copy_(act)
+    oa = O.default_args(n_rollout_threads=len(keep), **common)
+    opol = O.PolicyRef(oa, D, S, A)
+    opol.actor.load_state_dict({k: v.cpu() for k, v in pol.actor.state_dict().items()})
+    opol.critic.load_state_dict({k: v.cpu() for k, v in pol.critic.state_dict().items()})
+    ob = O.BufferRef(oa, Ma, D, S, A)
+    for n in BUF_NAMES:
+        getattr(ob, n)[...] = getattr(buf, n)[:, keep].cpu().numpy()
+    torch.manual_seed(3)
+    perms = [torch.randperm((T * len(keep) * Ma) // L).numpy() for _ in range(2)]
+    oinfo = O.train_ref(oa, opol, None, ob, perms=perms)
+    torch.manual_seed(5)
+    info = tr.train(buf)
+    for k in oinfo:
+        if k != "ratio":
+            close(info[k], oinfo[k], 2e-4, 1e-6, k)
+    for net, onet in ((pol.actor, opol.actor), (pol.critic, opol.critic)):
+        for k, v in net.state_dict().items():
+            close(v, onet.state_dict()[k].numpy(), 2e-4, 1e-5, k)
