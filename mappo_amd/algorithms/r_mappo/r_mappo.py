@@ -55,6 +55,7 @@ class R_MAPPO():
         self._concurrent_update = bool(getattr(args, "concurrent_update", False))
         self._graphs = {}
         self._dp_graphs = {}                       # data-parallel runs: hipGraphs of the collective-free segments
+        self._graph_buffers = {}                   # id(buffer) -> buffer: referenced for as long as its graphs are cached
 
         assert (self._use_popart and self._use_valuenorm) == False, \
             "self._use_popart and self._use_valuenorm can not be set True simultaneously"
@@ -262,7 +263,7 @@ class R_MAPPO():
         if not (self._use_graph and static and self._dist is None):
             body()
             return self._finish_train_info()
-        key = (id(buffer), bool(update_actor), bool(after_update))
+        key = (self._buffer_key(buffer), bool(update_actor), bool(after_update))
         state = self._graphs.get(key)
         if state is None:
             body()                                                         # eager: allocates workspaces, sets attributes
@@ -276,6 +277,14 @@ class R_MAPPO():
                 self._graphs[key] = state = g
             state.replay()
         return self._finish_train_info()
+
+    def _buffer_key(self, buffer):
+        """Cache key of the captured graphs of a buffer.  The trainer keeps the buffer alive while it holds graphs recorded
+        against its addresses, so the key (its id) cannot be reused by another object."""
+        k = id(buffer)
+        held = self._graph_buffers.setdefault(k, buffer)
+        assert held is buffer
+        return k
 
     def _sync_actor_mode(self, update_actor):
         """Host-side switches of update_actor (torch >= 2: grad None => Adam skips the actor), applied eagerly before the
@@ -297,7 +306,7 @@ class R_MAPPO():
         self._zbuf.zero_()
         whole = self.num_mini_batch == 1 and not self._exact_order
         dp_graph = self._dist is not None and self._use_graph and whole and self._fused and self._dist.world_is_gpu
-        key = (id(buffer), bool(update_actor))
+        key = (self._buffer_key(buffer), bool(update_actor))
         self._epochs = None
         if whole and self._fused and (self._dist is None or dp_graph) and not self._concurrent_update \
                 and os.environ.get("MAPPO_EPOCH_BATCH", "1") != "0":
