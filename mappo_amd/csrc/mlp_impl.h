@@ -1297,6 +1297,12 @@ int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, di
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st);
 int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa,
                                 const FwdArgs &a, const Wide16Args &wc, const FwdArgs &c, int nA);
+// split-K variants (one tile per 4-wave workgroup): step-sized batches
+int wide16_launch_forward_sk(int mode, bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a,
+                             const char *who);
+int wide16_launch_features_sk_dual(bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                   const Wide16Args &wc, const FwdArgs &c, int nA);
+#define WIDE_SK_MAX_TILES 256          // per network: above, the streamed kernels fill the chip
 
 #ifdef MLP_TU_WIDE
 template <int NCH>
@@ -1372,6 +1378,50 @@ int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 b
   if (ln == 0) return relu ? wide16_features_dual_nw<true, 0>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 0>(small, grid, block, lds_bytes, st, d);
   if (ln == 1) return relu ? wide16_features_dual_nw<true, 1>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 1>(small, grid, block, lds_bytes, st, d);
   return relu ? wide16_features_dual_nw<true, 2>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 2>(small, grid, block, lds_bytes, st, d);
+}
+
+template <bool R, int L, int MODE>
+static int wide16_forward_sk_one(dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_sk_kernel<R, L, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
+  PROF_LAUNCH(pid, (wide_forward16_sk_kernel<R, L, MODE>), grid, dim3(256), lds_bytes, st, w, a);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+static int wide16_forward_sk_mode(int mode, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
+  if (mode == 0) return wide16_forward_sk_one<R, L, 0>(grid, lds_bytes, st, w, a, who);
+  if (mode == 1) return wide16_forward_sk_one<R, L, 1>(grid, lds_bytes, st, w, a, who);
+  return wide16_forward_sk_one<R, L, 2>(grid, lds_bytes, st, w, a, who);
+}
+int wide16_launch_forward_sk(int mode, bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a,
+                             const char *who) {
+  if (ln == 0) return relu ? wide16_forward_sk_mode<true, 0>(mode, grid, lds_bytes, st, w, a, who) : wide16_forward_sk_mode<false, 0>(mode, grid, lds_bytes, st, w, a, who);
+  if (ln == 1) return relu ? wide16_forward_sk_mode<true, 1>(mode, grid, lds_bytes, st, w, a, who) : wide16_forward_sk_mode<false, 1>(mode, grid, lds_bytes, st, w, a, who);
+  return relu ? wide16_forward_sk_mode<true, 2>(mode, grid, lds_bytes, st, w, a, who) : wide16_forward_sk_mode<false, 2>(mode, grid, lds_bytes, st, w, a, who);
+}
+template <bool R, int L>
+static int wide16_features_sk_dual_one(dim3 grid, size_t lds_bytes, hipStream_t st, const WideDualArgs &d) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_sk_dual_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    attr_set = true;
+  }
+  PROF_LAUNCH(MAPPO_PROF_MLP_FWD, (wide_features16_sk_dual_kernel<R, L>), grid, dim3(256), lds_bytes, st, d);
+  return MAPPO_OK;
+}
+int wide16_launch_features_sk_dual(bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                   const Wide16Args &wc, const FwdArgs &c, int nA) {
+  WideDualArgs d;
+  d.wa = wa; d.wc = wc; d.a = a; d.c = c; d.nA = nA;
+  if (ln == 0) return relu ? wide16_features_sk_dual_one<true, 0>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 0>(grid, lds_bytes, st, d);
+  if (ln == 1) return relu ? wide16_features_sk_dual_one<true, 1>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 1>(grid, lds_bytes, st, d);
+  return relu ? wide16_features_sk_dual_one<true, 2>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 2>(grid, lds_bytes, st, d);
 }
 
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st) {
@@ -1657,8 +1707,13 @@ extern "C" int mappo_mlp_features_dual(const float *params_a, const mappo_net_de
     bool sa, sc;
     if (int rcp = wide_forward_prepare(a, wa, lba, ga, ba, sa, "mlp_features_dual")) return rcp;
     if (int rcp = wide_forward_prepare(c, wc, lbc, gc, bc, sc, "mlp_features_dual")) return rcp;
-    if (int rcw = wide16_launch_features_dual(desc_a->use_relu != 0, desc_a->layer_N, sa, dim3(ga.x + gc.x), ba, lba > lbc ? lba : lbc,
-                                              as_stream(stream), wa, a, wc, c, (int)ga.x))
+    const int64_t nt16 = (B + 15) / 16;
+    if (nt16 <= WIDE_SK_MAX_TILES && !getenv("MAPPO_WIDE_NO_SK")) {
+      if (int rcw = wide16_launch_features_sk_dual(desc_a->use_relu != 0, desc_a->layer_N, dim3((unsigned)(2 * nt16)), lba > lbc ? lba : lbc,
+                                                   as_stream(stream), wa, a, wc, c, (int)nt16))
+        return rcw;
+    } else if (int rcw = wide16_launch_features_dual(desc_a->use_relu != 0, desc_a->layer_N, sa, dim3(ga.x + gc.x), ba, lba > lbc ? lba : lbc,
+                                                     as_stream(stream), wa, a, wc, c, (int)ga.x))
       return rcw;
     MAPPO_CHECK_LAUNCH("mlp_features_dual");
     return MAPPO_OK;
@@ -1788,6 +1843,12 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
       dim3 g2, b2;
       bool small;
       if (int rcp = wide_forward_prepare(a, w, lb, g2, b2, small, who)) return rcp;
+      const int64_t nt16 = (a.B + 15) / 16;
+      if (nt16 <= WIDE_SK_MAX_TILES && !getenv("MAPPO_WIDE_NO_SK")) {          // step-sized batch: one tile per 4-wave workgroup, split-K
+        if (int rcw = wide16_launch_forward_sk(MODE, a.desc.use_relu != 0, LN, dim3((unsigned)nt16), lb, st, w, a, who)) return rcw;
+        MAPPO_CHECK_LAUNCH(who);
+        return MAPPO_OK;
+      }
       if (int rcw = wide16_launch_forward(MODE, a.desc.use_relu != 0, LN, small, g2, b2, lb, st, w, a, who)) return rcw;
       MAPPO_CHECK_LAUNCH(who);
       return MAPPO_OK;

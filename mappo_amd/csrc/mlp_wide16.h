@@ -445,6 +445,154 @@ __global__ __launch_bounds__(64 * NW, 2) void wide_features16_dual_kernel(WideDu
   else wide_forward16_body<RELU, LN, 2, NW, 8>(d.wc, d.c, lds, sW, sB, (int)blockIdx.x - d.nA, (int)gridDim.x - d.nA);
 }
 
+// ---- split-K forward for step-sized batches (a rollout step of configs[3] is 40 tiles per network) --------------------------
+// With that few tiles the streamed kernel above is one latency chain per workgroup: 3..8 chunks x (L2 fetch, LDS, barrier, 64
+// MFMAs on ONE wave per SIMD).  Here a workgroup of 4 waves owns ONE tile and splits the input columns: wave w takes the
+// 64-column chunks w, w + 4 of the tile's rows AND of W1 — its A operands come straight from global memory (16-byte loads, no
+// LDS staging, no chunk barriers: each weight is used by exactly one wave), everything is requested up front (ONE memory
+// latency), then <= 128 MFMAs per wave, and the four partial accumulators meet in LDS.  The B operand is the full LayerNorm
+// output  gamma0 xhat0 + beta0  (the affine applied to the registers), so the weights are used raw and no folded bias is needed.
+// The LayerNorm statistics over the whole row are two small exchanges (exact two-pass form).  Wave 0 then runs the
+// register-resident tail.  A workgroup walking several tiles keeps its A operands.
+struct SkShared {
+  float sS[4][16], sV[4][16];                                 // per-wave partial sums / centred squares of the 16 samples
+  float4 sAcc[3][4][64];                                      // partial accumulators of waves 1..3
+};
+
+template <bool RELU, int LN, int MODE>
+__device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, const FwdArgs &p, float *lds, SkShared &sh, const int bid, const int nb) {
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = w.D;
+  const bool fnorm = w.fn_w >= 0;
+  const bool al4 = (D & 3) == 0;
+  const float inv_D = 1.0f / (float)D;
+  const int c_last = (D + 63) / 64 - 1;
+  const int64_t n_tiles = (w.B + 15) / 16;
+  if (bid >= n_tiles) return;                                 // (uniform; never more workgroups than tiles)
+  stage_all_weights<LN>(lds, p.map, p.params, p.off, p.desc);  // everything but W1, for wave 0's tail (first barrier below)
+  // ---- this wave's columns: chunks wave, wave + 4; their W1 rows, gamma0, beta0 (zeros beyond the row) ----
+  f32x4 A[2][4][4];                                           // [chunk j][bo][jj]: W1[16 bo + n][64 c + 16 jj + 4 q .. + 3]
+  f32x4 gam[2][4], bet[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = wave + 4 * j;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int k = 64 * c + 16 * jj + 4 * q;
+      if (c <= c_last) {
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) A[j][bo][jj] = ld4_row(w.params + w.w1 + (size_t)(16 * bo + n) * D, k, D, al4);
+        gam[j][jj] = fnorm ? ld4_row(w.params + w.fn_w, k, D, al4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        bet[j][jj] = fnorm ? ld4_row(w.params + w.fn_b, k, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int bo = 0; bo < 4; ++bo) A[j][bo][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gam[j][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; bet[j][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  const int jq = lane & 15;
+  float *tZ = lds + p.map.tiles;                               // wave 0's logits tile
+  for (int64_t tile = bid; tile < n_tiles; tile += nb) {
+    const int64_t i = tile * 16 + n;
+    const bool ok = i < w.B;
+    const int64_t row = ok ? (w.rows ? (int64_t)w.rows[i] : i) : 0;
+    const float *xr = w.x + row * D;
+    f32x4 xq[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = wave + 4 * j;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+        xq[j][jj] = (c <= c_last) ? ld4_row(xr, 64 * c + 16 * jj + 4 * q, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (fnorm) {
+      f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) s4 += xq[j][jj];
+      const float ps = quad_sum16((s4[0] + s4[1]) + (s4[2] + s4[3]));
+      if (q == 0) sh.sS[wave][n] = ps;
+      __syncthreads();
+      const float mean = ((sh.sS[0][n] + sh.sS[1][n]) + (sh.sS[2][n] + sh.sS[3][n])) * inv_D;
+      const f32x4 mean4 = {mean, mean, mean, mean};
+      f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = wave + 4 * j;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          f32x4 d = xq[j][jj] - mean4;
+          if (c >= c_last) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) d[t] = (64 * c + 16 * jj + 4 * q + t < D) ? d[t] : 0.f;
+          }
+          xq[j][jj] = d; v4 += d * d;
+        }
+      }
+      const float pv = quad_sum16((v4[0] + v4[1]) + (v4[2] + v4[3]));
+      if (q == 0) sh.sV[wave][n] = pv;
+      __syncthreads();
+      const float rstd = 1.0f / sqrtf(((sh.sV[0][n] + sh.sV[1][n]) + (sh.sV[2][n] + sh.sV[3][n])) * inv_D + LN_EPS);
+      const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) xq[j][jj] = xq[j][jj] * rstd4 * gam[j][jj] + bet[j][jj];
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) acc[bo] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (wave + 4 * j <= c_last) {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) acc[bo] = mfma16(A[j][bo][jj][t], xq[j][jj][t], acc[bo]);
+      }
+    }
+    if (wave > 0) {
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) sh.sAcc[wave - 1][bo][lane] = make_float4(acc[bo][0], acc[bo][1], acc[bo][2], acc[bo][3]);
+    }
+    __syncthreads();                                           // partial accumulators (and, first tile, the staged weights) are in LDS
+    if (wave == 0) {
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) {
+        const f32x4 b1 = ld4u(w.params + w.b1 + 16 * bo + 4 * q);
+#pragma unroll
+        for (int sw = 0; sw < 3; ++sw) {
+          const float4 t = sh.sAcc[sw][bo][lane];
+          acc[bo][0] += t.x; acc[bo][1] += t.y; acc[bo][2] += t.z; acc[bo][3] += t.w;
+        }
+        acc[bo] += b1;
+      }
+      forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, jq, q, tZ);
+    }
+    __syncthreads();                                           // sAcc / sS / sV free for the next tile
+  }
+}
+
+template <bool RELU, int LN, int MODE>
+__global__ __launch_bounds__(256, 1) void wide_forward16_sk_kernel(Wide16Args w, FwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ SkShared sh;
+  wide_forward16_sk_body<RELU, LN, MODE>(w, p, lds, sh, blockIdx.x, gridDim.x);
+}
+
+template <bool RELU, int LN>
+__global__ __launch_bounds__(256, 1) void wide_features16_sk_dual_kernel(WideDualArgs d) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ SkShared sh;
+  if ((int)blockIdx.x < d.nA) wide_forward16_sk_body<RELU, LN, 2>(d.wa, d.a, lds, sh, blockIdx.x, d.nA);
+  else wide_forward16_sk_body<RELU, LN, 2>(d.wc, d.c, lds, sh, (int)blockIdx.x - d.nA, (int)gridDim.x - d.nA);
+}
+
 // ------------------------------------------------------------------------------------------------------------------------
 // wide_l1_bwd16_kernel — weight gradient of layer 1 and the feature-norm gradients for in_dim 65..512 from dz1 and the row
 // statistics the forward left (workspace layout below):

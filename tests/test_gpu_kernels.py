@@ -275,7 +275,9 @@ NET_CASES = [  # D, A, relu, layer_N, feature_norm, B
     (33, 32, False, 2, True, 130), (18, 5, True, 1, True, 1),
     # wide observations (K-chunked layer 1): SMAC MMM2 shapes (BASELINE configs[3]) and the 512-wide stress config
     (176, 18, True, 1, True, 300), (322, 1, True, 1, True, 257), (512, 5, False, 1, True, 100), (70, 3, True, 1, False, 64),
-    (130, 1, True, 0, True, 33)]
+    (130, 1, True, 0, True, 33),
+    # more than 256 tiles: the streamed wide forward (below that the split-K one-tile-per-workgroup kernel runs)
+    (322, 1, True, 1, True, 4200), (512, 5, True, 1, True, 4133)]
 
 
 @pytest.mark.parametrize("D,A,relu,LN,fn,B", NET_CASES)
