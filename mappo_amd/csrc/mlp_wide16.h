@@ -410,6 +410,66 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   }
 }
 
+// Everything the register-resident tail (mlp_fwd16.h) reads from LDS — the per-feature vectors from b1 on, W2.., the head —
+// staged with ONE memory latency: every global load is issued before the first LDS store (stage_all_weights walks the
+// matrices one after the other: four to five dependent L2 round trips, most of a step-sized launch).  W1 and the feature-norm
+// vectors are not staged: the wide kernels read them from global memory.  256 or 512 threads.
+template <int LN>
+__device__ __forceinline__ void stage_tail_1shot(float *lds, const LdsMap &m, const float *__restrict__ params, const NetOff &o,
+                                                 const mappo_net_desc &d) {
+  const int A = d.out_dim, nthr = blockDim.x, tid = threadIdx.x;
+  constexpr int NVEC = 3 * HID * (1 + LN) + 32, JV = (NVEC + 255) / 256;
+  float vv[JV]; int vd[JV];
+#pragma unroll
+  for (int j = 0; j < JV; ++j) {
+    const int e = j * nthr + tid;
+    int src = -1, dst = -1;
+    if (e < 3 * HID) { dst = m.b1 + e; src = o.b1 + e; }
+    else if (e < 3 * HID * (1 + LN)) {
+      const int i = e - 3 * HID, l = i / (3 * HID), r = i - l * 3 * HID;
+      dst = (l == 0 ? m.b2[0] : m.b2[LN > 1 ? 1 : 0]) + r;
+      src = (l == 0 ? o.b2[0] : o.b2[LN > 1 ? 1 : 0]) + r;
+    } else if (e < NVEC) { const int i = e - 3 * HID * (1 + LN); dst = m.bh + i; if (i < A) src = o.bh + i; }
+    const float ld = params[src >= 0 ? src : 0];
+    vv[j] = src >= 0 ? ld : 0.f; vd[j] = dst;
+  }
+  f32x4 w2v[LN > 0 ? LN : 1][4], whv[2];
+#pragma unroll
+  for (int l = 0; l < LN; ++l)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w2v[l][j] = ld4u(params + o.w2[l] + 4 * min(j * nthr + tid, 1023));
+  const int n4_h = 16 * A;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) whv[j] = ld4u(params + o.wh + 4 * min(j * nthr + tid, n4_h - 1));
+  // ---- stores ----
+#pragma unroll
+  for (int j = 0; j < JV; ++j) if (vd[j] >= 0) lds[vd[j]] = vv[j];
+#pragma unroll
+  for (int l = 0; l < LN; ++l)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = j * nthr + tid;
+      if (i < 1024) {
+        const int f = i >> 4, k = (i & 15) << 2;                 // element 4 i = W2[f][k .. k + 3] -> dst[k * WP + f]
+#pragma unroll
+        for (int c = 0; c < 4; ++c) lds[m.w2[l] + (k + c) * WP + f] = w2v[l][j][c];
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = j * nthr + tid;
+    if (i < n4_h) {
+      const int a = i >> 4, k = (i & 15) << 2;                   // Wh[a][k .. k + 3] -> dst[k * HP + a]
+#pragma unroll
+      for (int c = 0; c < 4; ++c) lds[m.wh + (k + c) * HP + a] = whv[j][c];
+    }
+  }
+  for (int e = tid; e < HID * (32 - A); e += nthr) {             // columns a >= A of the head are zero
+    const int k = e / (32 - A), a = A + e - k * (32 - A);
+    lds[m.wh + k * HP + a] = 0.f;
+  }
+}
+
 // The whole forward of a wide-input network in one launch (rollout: get_actions / get_values / trunk features): layer 1 as above,
 // then the register-resident 16x16x4 tail of the narrow kernels (mlp_fwd16.h) on the same tile.
 template <bool RELU, int LN, int MODE, int NW, int NCH>
@@ -419,7 +479,7 @@ __device__ __forceinline__ void wide_forward16_body(const Wide16Args &w, const F
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   float *tZ = lds + p.map.tiles + wave * p.map.wave_stride;
   wide16_layer1<NCH, NW>(w, sW, sB, bid, nb,
-    [&]() __attribute__((always_inline)) { stage_all_weights<LN>(lds, p.map, p.params, p.off, p.desc); },    // everything but W1 (streamed in chunks)
+    [&]() __attribute__((always_inline)) { stage_tail_1shot<LN>(lds, p.map, p.params, p.off, p.desc); },    // everything but W1 (streamed in chunks)
     [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
       forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, j, q, tZ);
     });
@@ -470,7 +530,6 @@ __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, cons
   const int c_last = (D + 63) / 64 - 1;
   const int64_t n_tiles = (w.B + 15) / 16;
   if (bid >= n_tiles) return;                                 // (uniform; never more workgroups than tiles)
-  stage_all_weights<LN>(lds, p.map, p.params, p.off, p.desc);  // everything but W1, for wave 0's tail (first barrier below)
   // ---- this wave's columns: chunks wave, wave + 4; their W1 rows, gamma0, beta0 (zeros beyond the row) ----
   f32x4 A[2][4][4];                                           // [chunk j][bo][jj]: W1[16 bo + n][64 c + 16 jj + 4 q .. + 3]
   f32x4 gam[2][4], bet[2][4];
@@ -507,6 +566,8 @@ __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, cons
       for (int jj = 0; jj < 4; ++jj)
         xq[j][jj] = (c <= c_last) ? ld4_row(xr, 64 * c + 16 * jj + 4 * q, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (tile == bid)       // first tile: the tail's weights (everything but W1) go to LDS behind the loads above — one memory latency in all
+      stage_tail_1shot<LN>(lds, p.map, p.params, p.off, p.desc);
     if (fnorm) {
       f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
