@@ -1844,8 +1844,11 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
       bool small;
       if (int rcp = wide_forward_prepare(a, w, lb, g2, b2, small, who)) return rcp;
       const int64_t nt16 = (a.B + 15) / 16;
-      if (nt16 <= WIDE_SK_MAX_TILES && !getenv("MAPPO_WIDE_NO_SK")) {          // step-sized batch: one tile per 4-wave workgroup, split-K
-        if (int rcw = wide16_launch_forward_sk(MODE, a.desc.use_relu != 0, LN, dim3((unsigned)nt16), lb, st, w, a, who)) return rcw;
+      int64_t sk_max = WIDE_SK_MAX_TILES;
+      if (const char *e = getenv("MAPPO_WIDE_SK_TILES")) sk_max = atoll(e);      // diagnostic override
+      if (nt16 <= sk_max && !getenv("MAPPO_WIDE_NO_SK")) {          // step-sized batch: one tile per 4-wave workgroup, split-K
+        const int64_t gsk = nt16 < NUM_CU ? nt16 : NUM_CU;          // (512 registers per wave: one workgroup per CU; more tiles are walked)
+        if (int rcw = wide16_launch_forward_sk(MODE, a.desc.use_relu != 0, LN, dim3((unsigned)gsk), lb, st, w, a, who)) return rcw;
         MAPPO_CHECK_LAUNCH(who);
         return MAPPO_OK;
       }
