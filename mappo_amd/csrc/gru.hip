@@ -99,6 +99,62 @@ __device__ __forceinline__ void stage_gru_all(float *lds, const GruLds &m, const
   }
 }
 
+// The same for the rollout step kernels (256 threads, both matrices + head), with ONE memory latency: every global load is issued
+// before the first LDS store.  stage_gru_all walks W_ih, W_hh, the bias / norm vectors and the head one after the other — about
+// fifteen dependent L2 round trips, half of a step-sized launch (a step is one tile per wave: nothing amortises the staging).
+__device__ __forceinline__ void stage_gru_step_1shot(float *lds, const GruLds &m, const float *__restrict__ params, const NetOff &o, int A) {
+  const int tid = threadIdx.x;                                 // blockDim.x == 256
+  constexpr int n4 = NG * HID / 4, J = n4 / 256;               // 12 float4 per thread and matrix
+  float4 wi[J], wh[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    wi[j] = reinterpret_cast<const float4 *>(params + o.gru_wih)[j * 256 + tid];
+    wh[j] = reinterpret_cast<const float4 *>(params + o.gru_whh)[j * 256 + tid];
+  }
+  // vectors: bih [192] | bhh [192] | rn_w [64] | rn_b [64] | bh [32] = 544 entries, 3 per thread
+  float vv[3]; int vd[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int e = j * 256 + tid;
+    int src = -1, dst = -1;
+    if (e < NG) { src = o.gru_bih + e; dst = m.bih + e; }
+    else if (e < 2 * NG) { src = o.gru_bhh + e - NG; dst = m.bhh + e - NG; }
+    else if (e < 2 * NG + HID) { src = o.rn_w + e - 2 * NG; dst = m.nw + e - 2 * NG; }
+    else if (e < 2 * NG + 2 * HID) { src = o.rn_b + e - 2 * NG - HID; dst = m.nb + e - 2 * NG - HID; }
+    else if (e < 2 * NG + 2 * HID + 32) { const int i = e - 2 * NG - 2 * HID; dst = m.bh + i; if (i < A) src = o.bh + i; }
+    const float ld = params[src >= 0 ? src : 0];
+    vv[j] = src >= 0 ? ld : 0.f; vd[j] = dst;
+  }
+  // head Wh [A][64]: 16 A float4 (A <= 32: two per thread)
+  const int n4h = 16 * A;
+  float4 hv[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) hv[j] = reinterpret_cast<const float4 *>(params + o.wh)[min(j * 256 + tid, n4h - 1)];
+  // ---- stores ----
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = j * 256 + tid, g = i >> 4, k = (i & 15) << 2;
+    float *di = lds + m.wih + k * GS + g, *dh = lds + m.whh + k * GS + g;
+    di[0] = wi[j].x; di[GS] = wi[j].y; di[2 * GS] = wi[j].z; di[3 * GS] = wi[j].w;
+    dh[0] = wh[j].x; dh[GS] = wh[j].y; dh[2 * GS] = wh[j].z; dh[3 * GS] = wh[j].w;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) if (vd[j] >= 0) lds[vd[j]] = vv[j];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int i = j * 256 + tid;
+    if (i < n4h) {
+      const int a = i >> 4, k = (i & 15) << 2;
+      float *d = lds + m.wh + k * HP + a;
+      d[0] = hv[j].x; d[HP] = hv[j].y; d[2 * HP] = hv[j].z; d[3 * HP] = hv[j].w;
+    }
+  }
+  for (int e = tid; e < HID * (32 - A); e += 256) {            // head columns a >= A are zero
+    const int k = e / (32 - A), a = A + e - k * (32 - A);
+    lds[m.wh + k * HP + a] = 0.f;
+  }
+}
+
 // row-major state [row][64] <-> accumulator layout (lane = sequence, registers = 32 of its 64 features)
 __device__ __forceinline__ void load_state_rowmajor(f32x16 (&h)[2], const float *__restrict__ src, int64_t row, bool ok, int half) {
 #pragma unroll
@@ -658,7 +714,10 @@ __device__ __forceinline__ void gru_step2_body(const GruFwdArgs &p, float *lds, 
   const GruLds &m = p.map;
   const int lane = threadIdx.x & (WAVE - 1), wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), l31 = lane & 31, half = lane >> 5;
   const int pair = wv >> 1, w = wv & 1;
-  stage_gru_all(lds, m, p.params, p.off, p.A, true, true);
+  if (blockDim.x == 256 && ((((uintptr_t)p.params) | (uintptr_t)(4 * p.off.gru_wih) | (uintptr_t)(4 * p.off.gru_whh) | (uintptr_t)(4 * p.off.wh)) & 15) == 0)
+    stage_gru_step_1shot(lds, m, p.params, p.off, p.A);
+  else
+    stage_gru_all(lds, m, p.params, p.off, p.A, true, true);
   __syncthreads();
   float *pb = lds + m.tiles + pair * STEP2_PAIR_FLOATS;
   float *tHm = pb, *tX = pb;                              // [64][TP] h * mask ; after the products: [16][64] partial logits of wave 1
