@@ -20,6 +20,7 @@
 //   gru_cell_bwd2_kernel  reverse time, two waves per 32 sequences: cell backward, carry = (W_hh^T dgh + dh*z) * mask;
 //                         writes dgi_T, dghn_T
 //   gru_wgrad_kernel      dW_ih, dW_hh, db_ih, db_hh = row-tile GEMMs over (dgi, x) and (dgh, hm) -> slabs
+#include <stdlib.h>
 #include "mlp_core.h"
 
 #define GS 193              // LDS row stride of the GRU weights (k-major: sW[k*GS + g], g < 192)
@@ -846,6 +847,172 @@ __device__ __forceinline__ void gru_step2_body(const GruFwdArgs &p, float *lds, 
     lds_barrier();                                        // the tiles are rewritten by the next trip
   }
 }
+// ---- rollout step, third form: one 16-row tile per 4-wave workgroup, the HIDDEN UNITS split over the waves -------------------
+// The two-waves-per-32-rows step above spends its time in the prologue (96 KB of GRU weights through LDS per workgroup) and in
+// 192 32x32x2 MFMAs per wave on one wave per SIMD: 19 us for a step whose arithmetic is tiny.  Here wave w of a workgroup owns
+// hidden units [16 w, 16 w + 16) of ONE 16-row tile on v_mfma_f32_16x16x4_f32:
+//   * its A operands are the 3 x 16 rows of W_ih and W_hh that produce those units' r / z / n gates, read STRAIGHT from global
+//     memory as 16-byte loads (24 per lane; every weight is used by exactly one wave: no LDS staging, no staging barrier);
+//   * the B operands are the tile's trunk features (feature-major xT: 16 dwords per lane) and h * mask (row-major: four 16-byte
+//     loads per lane); k-step (b, i) takes k = 16 b + 4 q + i, so for b = w the h operand IS the lane's own units' previous state;
+//   * 96 MFMAs per wave, gates and the state update per lane (4 units x 1 row), the new state goes out as 16-byte stores;
+//   * LayerNorm over the 64 units: two 4-wave exchanges of 16 floats (exact two-pass form); the head is split over k the same
+//     way (each wave multiplies its 16 normalised units), partial logits meet in LDS, wave 0 masks / samples / writes.
+// All loads of a workgroup are issued before anything waits: one memory latency per step.
+struct Step3Shared {
+  float sS[4][16], sV[4][16];
+  float4 sZ[3][2][64];                                        // partial logits of waves 1..3
+  float tZ[16][36];                                           // logits [sample][action] for the categorical epilogue
+};
+typedef float g4_t __attribute__((ext_vector_type(4)));
+typedef float g4u_t __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ g4_t g4_load(const float *p) { const g4u_t v = *reinterpret_cast<const g4u_t *>(p); g4_t r; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; return r; }
+__device__ __forceinline__ g4_t mfma16g(float a, float b, g4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float quad_sum16g(float v) { return xhalf_sum(xrow_sum(v)); }     // lanes n, n + 16, n + 32, n + 48
+
+template <int HM>
+__device__ __forceinline__ void gru_step3_body(const GruFwdArgs &p, Step3Shared &sh, const int bid, const int nb) {
+  const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), n = lane & 15, q = lane >> 4;
+  const int n_tiles = (p.Nc + 15) / 16;
+  if (bid >= n_tiles) return;
+  const int64_t B = p.Nc;                                       // L == 1: column = sequence
+  const int A = p.A;
+  // ---- this wave's weights: rows 64 g + 16 w + n of W_ih / W_hh, columns 16 b + 4 q .. + 3 ----
+  g4_t wi[3][4], wh[3][4];
+  {
+    const float *ri = p.params + p.off.gru_wih + (size_t)(16 * w + n) * HID + 4 * q;
+    const float *rh = p.params + p.off.gru_whh + (size_t)(16 * w + n) * HID + 4 * q;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { wi[g][b] = g4_load(ri + g * HID * HID + 16 * b); wh[g][b] = g4_load(rh + g * HID * HID + 16 * b); }
+  }
+  const int u0 = 16 * w + 4 * q;                                // this lane's four hidden units
+  const g4_t bir = g4_load(p.params + p.off.gru_bih + u0), biz = g4_load(p.params + p.off.gru_bih + HID + u0), bin = g4_load(p.params + p.off.gru_bih + 2 * HID + u0);
+  const g4_t bhr = g4_load(p.params + p.off.gru_bhh + u0), bhz = g4_load(p.params + p.off.gru_bhh + HID + u0), bhn = g4_load(p.params + p.off.gru_bhh + 2 * HID + u0);
+  const g4_t nw4 = g4_load(p.params + p.off.rn_w + u0), nb4 = g4_load(p.params + p.off.rn_b + u0);
+  // head rows a = 16 bo + n (zero beyond A), columns = this lane's units
+  g4_t hw[2];
+#pragma unroll
+  for (int bo = 0; bo < 2; ++bo) {
+    const int a = 16 * bo + n;
+    const g4_t t = g4_load(p.params + p.off.wh + (size_t)min(a, A - 1) * HID + u0);
+    hw[bo] = a < A ? t : g4_t{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int tile = bid; tile < n_tiles; tile += nb) {
+    const int c = tile * 16 + n;
+    const bool ok = c < p.Nc;
+    const int cc = ok ? c : 0;
+    const int64_t hrow = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
+    const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[cc] : (int64_t)cc] : 0.f;
+    uint32_t dead = 0u;
+    if (HM == 2 && p.avail && w == 0 && q == 0) dead = avail_dead_mask(p.avail + (int64_t)cc * A, A);    // the sampling lanes
+    g4_t x[4], hm[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[b][i] = p.xT[(int64_t)(16 * b + 4 * q + i) * B + cc];
+      hm[b] = g4_load(p.h0 + hrow * HID + 16 * b + 4 * q);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { x[b][i] = ok ? x[b][i] : 0.f; hm[b][i] *= mk; }
+    }
+    g4_t ar = bir + bhr, az = biz + bhz, ain = bin, ahn = bhn;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ar = mfma16g(wi[0][b][i], x[b][i], ar);
+        az = mfma16g(wi[1][b][i], x[b][i], az);
+        ain = mfma16g(wi[2][b][i], x[b][i], ain);
+        ar = mfma16g(wh[0][b][i], hm[b][i], ar);
+        az = mfma16g(wh[1][b][i], hm[b][i], az);
+        ahn = mfma16g(wh[2][b][i], hm[b][i], ahn);
+      }
+    // the lane's own units' previous state = the h operand of k-block b == w
+    const g4_t hprev = w == 0 ? hm[0] : (w == 1 ? hm[1] : (w == 2 ? hm[2] : hm[3]));
+    g4_t h;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float gr = sigmoidf_(ar[i]), gz = sigmoidf_(az[i]);
+      const float gn = tanhf_(ain[i] + gr * ahn[i]);
+      h[i] = (1.f - gz) * gn + gz * hprev[i];
+    }
+    if (p.h_last && ok) {
+      g4u_t o; o[0] = h[0]; o[1] = h[1]; o[2] = h[2]; o[3] = h[3];
+      *reinterpret_cast<g4u_t *>(p.h_last + (int64_t)c * HID + u0) = o;
+    }
+    // ---- LayerNorm over the 64 units of a row (rnn.py:22,79): exact two-pass, two exchanges ----
+    const float ps = quad_sum16g((h[0] + h[1]) + (h[2] + h[3]));
+    if (q == 0) sh.sS[w][n] = ps;
+    __syncthreads();
+    const float mean = ((sh.sS[0][n] + sh.sS[1][n]) + (sh.sS[2][n] + sh.sS[3][n])) * (1.f / HID);
+    g4_t d = h - g4_t{mean, mean, mean, mean};
+    const float pv = quad_sum16g((d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]));
+    if (q == 0) sh.sV[w][n] = pv;
+    __syncthreads();
+    const float rstd = 1.0f / sqrtf(((sh.sV[0][n] + sh.sV[1][n]) + (sh.sV[2][n] + sh.sV[3][n])) * (1.f / HID) + LN_EPS);
+    const g4_t y = d * g4_t{rstd, rstd, rstd, rstd} * nw4 + nb4;
+    // ---- head, split over k: this wave's 16 units (k-step i <-> unit 16 w + 4 q + i) ----
+    g4_t z[2] = {g4_t{0.f, 0.f, 0.f, 0.f}, g4_t{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      z[0] = mfma16g(hw[0][i], y[i], z[0]);
+      if (A > 16) z[1] = mfma16g(hw[1][i], y[i], z[1]);
+    }
+    if (w > 0) {
+      sh.sZ[w - 1][0][lane] = make_float4(z[0][0], z[0][1], z[0][2], z[0][3]);
+      sh.sZ[w - 1][1][lane] = make_float4(z[1][0], z[1][1], z[1][2], z[1][3]);
+    }
+    __syncthreads();
+    if (w == 0) {
+      // lane (n, q) holds logits of actions 16 bo + 4 q + i for row n
+#pragma unroll
+      for (int bo = 0; bo < 2; ++bo) {
+#pragma unroll
+        for (int sw = 0; sw < 3; ++sw) {
+          const float4 t = sh.sZ[sw][bo][lane];
+          z[bo][0] += t.x; z[bo][1] += t.y; z[bo][2] += t.z; z[bo][3] += t.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int a = 16 * bo + 4 * q + i;
+          if (a < A) {
+            const float v = z[bo][i] + p.params[p.off.bh + a];
+            if (HM == 1) { if (ok) p.out[(int64_t)c * A + a] = v; }
+            else sh.tZ[n][a] = v;
+          }
+        }
+      }
+      if (HM == 2) {
+        wave_lds_sync();
+        if (q == 0 && ok) {
+          const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+          float action, logp;
+          categorical_act_mask(&sh.tZ[n][0], A, dead, p.deterministic != 0, p.seed, ctr, (uint64_t)c, action, logp);
+          p.actions[c] = action;
+          p.logp[c] = logp;
+        }
+      }
+    }
+    __syncthreads();                                            // the exchange buffers are rewritten by the next tile
+  }
+}
+
+template <int HM>
+__global__ __launch_bounds__(256, 1) void gru_step3_kernel(GruFwdArgs p) {
+  __shared__ Step3Shared sh;
+  gru_step3_body<HM>(p, sh, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256, 1) void gru_step3_dual_kernel(GruFwdArgs a, GruFwdArgs c, int nA) {
+  __shared__ Step3Shared sh;
+  if ((int)blockIdx.x < nA) gru_step3_body<2>(a, sh, blockIdx.x, nA);
+  else gru_step3_body<1>(c, sh, blockIdx.x - nA, gridDim.x - nA);
+}
+
 template <int HM>
 __global__ __launch_bounds__(256, 1) void gru_step2_kernel(GruFwdArgs p) {
   extern __shared__ __align__(16) float lds[];
@@ -1256,7 +1423,16 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
     MAPPO_CHECK_LAUNCH("gru_forward");
     return MAPPO_OK;
   }
-  if (!giT && !scratch && L == 1 && head_mode != 0) {       // rollout / get_values step: two waves per 32 rows
+  if (!giT && !scratch && L == 1 && head_mode != 0 && !(getenv("MAPPO_GRU_STEP3") && getenv("MAPPO_GRU_STEP3")[0] == '0')) {
+    // rollout / get_values step: one 16-row tile per 4-wave workgroup, hidden units split over the waves
+    const int nt16 = (Nc + 15) / 16;
+    const int g3 = nt16 < 2 * NUM_CU ? nt16 : 2 * NUM_CU;
+    if (head_mode == 1) hipLaunchKernelGGL(gru_step3_kernel<1>, dim3(g3), dim3(4 * WAVE), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(gru_step3_kernel<2>, dim3(g3), dim3(4 * WAVE), 0, as_stream(stream), a);
+    MAPPO_CHECK_LAUNCH("gru_forward");
+    return MAPPO_OK;
+  }
+  if (!giT && !scratch && L == 1 && head_mode != 0) {       // (MAPPO_GRU_STEP3=0) two waves per 32 rows
     a.map = gru_lds(0, 0, true);
     const size_t bytes = (size_t)(a.map.total + 2 * STEP2_PAIR_FLOATS) * sizeof(float);
     MAPPO_REQUIRE(bytes <= LDS_DYN_MAX, "gru_forward: needs %zu B of LDS", bytes);
@@ -1319,6 +1495,13 @@ extern "C" int mappo_gru_step_dual(const float *actor_params, const mappo_net_de
   a.deterministic = deterministic; a.seed = seed; a.counter = counter; a.counter_dev = counter_dev;
   c.params = critic_params; c.off = net_offsets(*critic_desc); c.xT = critic_featT; c.h0 = critic_h0; c.masks = masks; c.L = 1; c.Nc = Nc;
   c.A = 1; c.head_mode = 1; c.h_last = critic_h_last; c.out = values;
+  if (!(getenv("MAPPO_GRU_STEP3") && getenv("MAPPO_GRU_STEP3")[0] == '0')) {
+    const int nt16 = (Nc + 15) / 16;
+    const int g3 = nt16 < NUM_CU ? nt16 : NUM_CU;
+    hipLaunchKernelGGL(gru_step3_dual_kernel, dim3(2 * g3), dim3(4 * WAVE), 0, as_stream(stream), a, c, g3);
+    MAPPO_CHECK_LAUNCH("gru_step_dual");
+    return MAPPO_OK;
+  }
   a.map = c.map = gru_lds(0, 0, true);
   const size_t bytes = (size_t)(a.map.total + 2 * STEP2_PAIR_FLOATS) * sizeof(float);
   MAPPO_REQUIRE(bytes <= LDS_DYN_MAX, "gru_step_dual: needs %zu B of LDS", bytes);
