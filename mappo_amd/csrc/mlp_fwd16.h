@@ -125,6 +125,202 @@ __device__ __forceinline__ void forward16_tail(const FwdArgs &p, float *lds, con
   }
 }
 
+// ---- the same forward with the weights in REGISTERS -------------------------------------------------------------------------
+// A rollout-sized launch is one tile per wave: staging the weights through LDS (global -> registers -> LDS -> barrier -> scalar
+// operand reads) is then most of the launch.  Here every wave loads its A operands straight from global memory as 16-byte loads
+// (W1, W2.., head: <= 200 registers; the waves of a workgroup fetch the same lines, so L1 / L2 serve all but the first), along
+// with the per-feature vectors it needs as 4-wide registers, ALL issued before anything waits: one memory latency, no barrier,
+// no LDS except the logits tile of the sampling epilogue.  k-step (b, i) takes input / hidden feature 16 b + 4 q + i in every
+// layer.  (Rows of W1 are read up to 15 floats past in_dim — into the next row or the bias that follows W1 in the flat
+// parameter vector: finite values that meet zero inputs.)
+typedef float f32x4_ua __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ f32x4 ld4ua(const float *p) { const f32x4_ua v = *reinterpret_cast<const f32x4_ua *>(p); f32x4 r; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; return r; }
+
+// act + LayerNorm(64) with the affine in registers (g, t: features 16 b + 4 q + r of gamma / beta)
+template <bool RELU>
+__device__ __forceinline__ void act_ln16r(f32x4 (&acc)[4], const f32x4 (&g)[4], const f32x4 (&t)[4]) {
+  float s = 0.f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[b][r] = act_fwd<RELU>(acc[b][r]); s += acc[b][r]; }
+  const float mean = quad_sum16(s) * (1.f / HID);
+  float v = 0.f;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const float c = acc[b][r] - mean; v += c * c; }
+  const float rstd = 1.0f / sqrtf(quad_sum16(v) * (1.f / HID) + LN_EPS);
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[b][r] = (acc[b][r] - mean) * rstd * g[b][r] + t[b][r];
+}
+
+template <bool RELU, int LN, int MODE>
+__device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, const int bid, const int nb) {
+  const int n_waves = blockDim.x / WAVE;
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), j = lane & 15, q = lane >> 4;
+  const int D = p.desc.in_dim, A = p.desc.out_dim;
+  const int NB1 = (D + 15) >> 4;                                 // 16-wide k-blocks of the input layer
+  const int64_t n_tiles = (p.B + 15) / 16;
+  const bool fnorm = p.desc.use_feature_norm != 0;
+  const float inv_D = 1.0f / (float)D;
+  float *tZ = lds + wave * 16 * TP;                              // [16][TP] logits of this wave's samples (MODE 1)
+  int64_t tile = (int64_t)bid * n_waves + wave;
+  if (tile >= n_tiles) return;
+  const float *P = p.params;
+  // ---- weights and vectors of this lane (issued before the first wait) ----
+  f32x4 w1[4][4];                                                // [bo][b]: W1[16 bo + j][16 b + 4 q ..]
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (b < NB1) {
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) w1[bo][b] = ld4ua(P + o.w1 + (size_t)(16 * bo + j) * D + 16 * b + 4 * q);
+    }
+  f32x4 g0[4], t0[4];                                            // feature-norm affine of the inputs (zero beyond in_dim)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * b + 4 * q + r;
+      const bool in = fnorm && k < D;
+      const float gv = P[o.fn_w + min(k, D - 1)], tv = P[o.fn_b + min(k, D - 1)];
+      g0[b][r] = in ? gv : ((!fnorm && k < D) ? 1.f : 0.f);
+      t0[b][r] = in ? tv : 0.f;
+    }
+  f32x4 b1v[4], g1[4], t1[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) { b1v[b] = ld4ua(P + o.b1 + 16 * b + 4 * q); g1[b] = ld4ua(P + o.ln1_w + 16 * b + 4 * q); t1[b] = ld4ua(P + o.ln1_b + 16 * b + 4 * q); }
+  f32x4 w2[LN > 0 ? LN : 1][4][4], b2v[LN > 0 ? LN : 1][4], g2[LN > 0 ? LN : 1][4], t2[LN > 0 ? LN : 1][4];
+#pragma unroll
+  for (int l = 0; l < LN; ++l)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) w2[l][bo][b] = ld4ua(P + o.w2[l] + (size_t)(16 * bo + j) * HID + 16 * b + 4 * q);
+      b2v[l][b] = ld4ua(P + o.b2[l] + 16 * b + 4 * q); g2[l][b] = ld4ua(P + o.ln2_w[l] + 16 * b + 4 * q); t2[l][b] = ld4ua(P + o.ln2_b[l] + 16 * b + 4 * q);
+    }
+  constexpr int NBH = MODE == 1 ? 2 : (MODE == 0 ? 1 : 0);       // head blocks of 16 outputs (critic: row 0 only)
+  f32x4 wh[NBH > 0 ? NBH : 1][4];
+  f32x4 bhv[NBH > 0 ? NBH : 1];
+  if constexpr (NBH > 0) {
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo) {
+      const int a = 16 * bo + j;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const f32x4 t = ld4ua(P + o.wh + (size_t)min(a, A - 1) * HID + 16 * b + 4 * q);
+        wh[bo][b] = a < A ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const int ar = 16 * bo + 4 * q + r; const float bvv = P[o.bh + min(ar, A - 1)]; bhv[bo][r] = ar < A ? bvv : 0.f; }
+    }
+  }
+  for (; tile < n_tiles; tile += (int64_t)nb * n_waves) {
+    const int64_t i = tile * 16 + j;
+    const bool ok = i < p.B;
+    const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
+    const int64_t off = p.x_M ? (row / p.x_M) * p.x_sn + (row % p.x_M) * p.x_sm : row * D;
+    f32x4 x[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[b][r] = p.x[off + min(16 * b + 4 * q + r, D - 1)];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[b][r] = (ok && 16 * b + 4 * q + r < D) ? x[b][r] : 0.f;
+    if (fnorm) {
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) s += (x[b][0] + x[b][1]) + (x[b][2] + x[b][3]);
+      const float mean = quad_sum16(s) * inv_D;
+      float v = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float c = (16 * b + 4 * q + r < D) ? x[b][r] - mean : 0.f; x[b][r] = c; v += c * c; }
+      const float rstd = 1.0f / sqrtf(quad_sum16(v) * inv_D + LN_EPS);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[b][r] = x[b][r] * rstd * g0[b][r] + t0[b][r];
+    }
+    // ---- layer 1 ----
+    f32x4 h[4];
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) h[bo] = b1v[bo];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+      if (b < NB1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int bo = 0; bo < 4; ++bo) h[bo] = mfma16(w1[bo][b][r], x[b][r], h[bo]);
+      }
+    act_ln16r<RELU>(h, g1, t1);
+#pragma unroll
+    for (int l = 0; l < LN; ++l) {
+      f32x4 h2[4];
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) h2[bo] = b2v[l][bo];
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int bo = 0; bo < 4; ++bo) h2[bo] = mfma16(w2[l][bo][b][r], h[b][r], h2[bo]);
+      act_ln16r<RELU>(h2, g2[l], t2[l]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) h[b] = h2[b];
+    }
+    // ---- head ----
+    if constexpr (MODE == 2) {
+      if (ok) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) p.out[(int64_t)(16 * b + 4 * q + r) * p.B + i] = h[b][r];
+      }
+    } else {
+      f32x4 z[NBH > 0 ? NBH : 1];
+#pragma unroll
+      for (int bo = 0; bo < NBH; ++bo) {
+        z[bo] = bhv[bo];
+        if (bo == 0 || A > 16) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z[bo] = mfma16(wh[bo][b][r], h[b][r], z[bo]);
+        }
+      }
+      if constexpr (MODE == 0) {
+        if (A == 1) { if (ok && q == 0) p.out[i] = z[0][0]; }
+        else if (ok) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int a = 4 * q + r; if (a < A) p.out[i * A + a] = z[0][r]; }     // (out_dim <= 16 through this path)
+        }
+      } else {
+#pragma unroll
+        for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { const int a = 16 * bo + 4 * q + r; if (a < A) tZ[j * TP + a] = z[bo][r]; }
+        wave_lds_sync();
+        if (ok && q == 0) {
+          const uint64_t ctr = p.counter + (p.counter_dev ? *p.counter_dev : 0ull);
+          float action, logp;
+          categorical_act_lane(tZ + j * TP, A, p.avail ? p.avail + i * A : nullptr, p.deterministic != 0, p.seed, ctr, (uint64_t)i, action, logp);
+          p.actions[i] = action;
+          p.logp[i] = logp;
+        }
+        wave_lds_sync();
+      }
+    }
+  }
+}
+
 // workgroup `bid` of `nb`; MODE 0: out[i] = value (critic, out_dim 1) | MODE 1: sample / argmax + log-prob (actor)
 // | MODE 2: the trunk's output (LayerNorm of the last hidden layer) feature-major, out[64][B] (recurrent networks)
 template <bool RELU, int LN, int MODE>

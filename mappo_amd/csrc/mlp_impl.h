@@ -700,8 +700,8 @@ template <bool RELU, int LN>
 __global__ __launch_bounds__(256, 1) void rollout_step_kernel(StepArgs s) {
   extern __shared__ __align__(16) float lds[];
   const int bid = blockIdx.x;
-  if (bid < s.nA) forward16_body<RELU, LN, 1>(s.a, lds, bid, s.nA);
-  else if (bid < s.nA + s.nC) forward16_body<RELU, LN, 0>(s.c, lds, bid - s.nA, s.nC);
+  if (bid < s.nA) forward16r_body<RELU, LN, 1>(s.a, lds, bid, s.nA);
+  else if (bid < s.nA + s.nC) forward16r_body<RELU, LN, 0>(s.c, lds, bid - s.nA, s.nC);
   else insert_mpe_body(s.ins, bid - s.nA - s.nC, s.nI);
 }
 
@@ -709,13 +709,13 @@ __global__ __launch_bounds__(256, 1) void rollout_step_kernel(StepArgs s) {
 template <bool RELU, int LN>
 __global__ __launch_bounds__(256, 1) void features16_kernel(FwdArgs a) {
   extern __shared__ __align__(16) float lds[];
-  forward16_body<RELU, LN, 2>(a, lds, blockIdx.x, gridDim.x);
+  forward16r_body<RELU, LN, 2>(a, lds, blockIdx.x, gridDim.x);
 }
 template <bool RELU, int LN>
 __global__ __launch_bounds__(256, 1) void features16_dual_kernel(FwdArgs a, FwdArgs c, int nA) {
   extern __shared__ __align__(16) float lds[];
-  if ((int)blockIdx.x < nA) forward16_body<RELU, LN, 2>(a, lds, blockIdx.x, nA);
-  else forward16_body<RELU, LN, 2>(c, lds, blockIdx.x - nA, gridDim.x - nA);
+  if ((int)blockIdx.x < nA) forward16r_body<RELU, LN, 2>(a, lds, blockIdx.x, nA);
+  else forward16r_body<RELU, LN, 2>(c, lds, blockIdx.x - nA, gridDim.x - nA);
 }
 
 // ------------------------------------------------------------------------------------------------
