@@ -1802,7 +1802,7 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
     i.rew_dst = rew_dst; i.mask_dst = mask_dst; i.N = (int)(B / M); i.M = M; i.D = actor_desc->in_dim; i.centralized = centralized;
     const int64_t total = B * (centralized ? (int64_t)M * i.D : i.D);
     int64_t ni = (total + 2047) / 2048;                  // ~8 elements per thread
-    s.nI = (int)(ni > 64 ? 64 : ni);
+    s.nI = (int)(ni > NUM_CU ? NUM_CU : ni);              // (64 insert workgroups became the long pole of the launch beyond ~2 000 threads)
   }
   dim3 grid((unsigned)(s.nA + s.nC + s.nI)), block(WAVE * nw);
   const bool relu = actor_desc->use_relu != 0;
