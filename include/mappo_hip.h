@@ -291,6 +291,14 @@ int mappo_gru_step_dual(const float *actor_params, const mappo_net_desc *actor_d
                         float *critic_h_last, const float *masks /*[Nc]*/, int32_t Nc, const float *avail /*[Nc][A] or NULL*/,
                         int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
                         float *logp, float *values, mappo_stream_t stream);
+/* The same step with the trunks included (in_dim <= 64, layer_N <= 1): obs / share_obs rows [Nc][in_dim] instead of precomputed
+ * features — mappo_mlp_features_dual + mappo_gru_step_dual in ONE launch (r_actor_critic.py:43-70,146-165 end to end). */
+int mappo_recurrent_step_dual(const float *actor_params, const mappo_net_desc *actor_desc, const float *obs,
+                              const float *actor_h0, float *actor_h_last, const float *critic_params,
+                              const mappo_net_desc *critic_desc, const float *share_obs, const float *critic_h0,
+                              float *critic_h_last, const float *masks, int32_t Nc, const float *avail, int32_t deterministic,
+                              uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions, float *logp,
+                              float *values, mappo_stream_t stream);
 /* Trunk features of two networks (same layer_N / activation, in_dim <= 64) on the same B rows in one launch. */
 int mappo_mlp_features_dual(const float *params_a, const mappo_net_desc *desc_a /*host*/, const float *x_a, float *featT_a,
                             const float *params_c, const mappo_net_desc *desc_c /*host*/, const float *x_c, float *featT_c,

@@ -22,6 +22,7 @@
 //   gru_wgrad_kernel      dW_ih, dW_hh, db_ih, db_hh = row-tile GEMMs over (dgi, x) and (dgh, hm) -> slabs
 #include <stdlib.h>
 #include "mlp_core.h"
+#include "mlp_trunk16r.h"
 
 #define GS 193              // LDS row stride of the GRU weights (k-major: sW[k*GS + g], g < 192)
 #define NG 192
@@ -362,6 +363,9 @@ struct GruFwdArgs {
   int deterministic;
   uint64_t seed, counter;
   const uint64_t *counter_dev;
+  // fused rollout step (gru_step3f_*): the trunk runs in the same launch on the rows x_rows [Nc][in_dim]
+  const float *x_rows;
+  mappo_net_desc desc;
 };
 
 // PRE_GI: input gates precomputed (training); HM: head mode 0 none | 1 out[B][A] | 2 sample.  Compile-time so that each use
@@ -870,7 +874,11 @@ __device__ __forceinline__ g4_t g4_load(const float *p) { const g4u_t v = *reint
 __device__ __forceinline__ g4_t mfma16g(float a, float b, g4_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float quad_sum16g(float v) { return xhalf_sum(xrow_sum(v)); }     // lanes n, n + 16, n + 32, n + 48
 
-template <int HM>
+// TR: 0 = trunk features from xT | 1 = fused, ReLU trunk | 2 = fused, tanh trunk;  TLN: the trunk's layer_N (fused only).
+// Fused: every wave of the workgroup runs the (narrow-input) trunk of the tile itself with the weights in registers
+// (mlp_trunk16r.h) — the trunk's output in the accumulator layout IS the B operand of the W_ih products, so there is nothing to
+// exchange — and the separate features launch (a ~10 us floor per step) disappears.
+template <int HM, int TR = 0, int TLN = 0>
 __device__ __forceinline__ void gru_step3_body(const GruFwdArgs &p, Step3Shared &sh, const int bid, const int nb) {
   const int lane = threadIdx.x & (WAVE - 1), w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), n = lane & 15, q = lane >> 4;
   const int n_tiles = (p.Nc + 15) / 16;
@@ -887,6 +895,8 @@ __device__ __forceinline__ void gru_step3_body(const GruFwdArgs &p, Step3Shared 
 #pragma unroll
       for (int b = 0; b < 4; ++b) { wi[g][b] = g4_load(ri + g * HID * HID + 16 * b); wh[g][b] = g4_load(rh + g * HID * HID + 16 * b); }
   }
+  Trunk16R<TLN> tw;
+  if constexpr (TR != 0) trunk16r_load<TLN>(tw, p.params, p.off, p.desc, n, q);
   const int u0 = 16 * w + 4 * q;                                // this lane's four hidden units
   const g4_t bir = g4_load(p.params + p.off.gru_bih + u0), biz = g4_load(p.params + p.off.gru_bih + HID + u0), bin = g4_load(p.params + p.off.gru_bih + 2 * HID + u0);
   const g4_t bhr = g4_load(p.params + p.off.gru_bhh + u0), bhz = g4_load(p.params + p.off.gru_bhh + HID + u0), bhn = g4_load(p.params + p.off.gru_bhh + 2 * HID + u0);
@@ -908,11 +918,24 @@ __device__ __forceinline__ void gru_step3_body(const GruFwdArgs &p, Step3Shared 
     uint32_t dead = 0u;
     if (HM == 2 && p.avail && w == 0 && q == 0) dead = avail_dead_mask(p.avail + (int64_t)cc * A, A);    // the sampling lanes
     g4_t x[4], hm[4];
+    if constexpr (TR != 0) {
+      const int D = p.desc.in_dim;
+      const float *xr = p.x_rows + (int64_t)cc * D;
+      f32x4 xin[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[b][i] = p.xT[(int64_t)(16 * b + 4 * q + i) * B + cc];
-      hm[b] = g4_load(p.h0 + hrow * HID + 16 * b + 4 * q);
+        for (int i = 0; i < 4; ++i) xin[b][i] = xr[min(16 * b + 4 * q + i, D - 1)];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) hm[b] = g4_load(p.h0 + hrow * HID + 16 * b + 4 * q);
+      trunk16r_apply<TR == 1, TLN>(tw, xin, x, D, ok, p.desc.use_feature_norm != 0, q);
+    } else {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[b][i] = p.xT[(int64_t)(16 * b + 4 * q + i) * B + cc];
+        hm[b] = g4_load(p.h0 + hrow * HID + 16 * b + 4 * q);
+      }
     }
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -1011,6 +1034,14 @@ __global__ __launch_bounds__(256, 1) void gru_step3_dual_kernel(GruFwdArgs a, Gr
   __shared__ Step3Shared sh;
   if ((int)blockIdx.x < nA) gru_step3_body<2>(a, sh, blockIdx.x, nA);
   else gru_step3_body<1>(c, sh, blockIdx.x - nA, gridDim.x - nA);
+}
+
+// trunk + GRU step + head of a recurrent actor AND critic (narrow inputs) in ONE launch
+template <int TR, int TLN>
+__global__ __launch_bounds__(256, 1) void gru_step3f_dual_kernel(GruFwdArgs a, GruFwdArgs c, int nA) {
+  __shared__ Step3Shared sh;
+  if ((int)blockIdx.x < nA) gru_step3_body<2, TR, TLN>(a, sh, blockIdx.x, nA);
+  else gru_step3_body<1, TR, TLN>(c, sh, blockIdx.x - nA, gridDim.x - nA);
 }
 
 template <int HM>
@@ -1512,6 +1543,42 @@ extern "C" int mappo_gru_step_dual(const float *actor_params, const mappo_net_de
   if (!attr) { if (int rc = raise_lds(gru_step2_dual_kernel, "gru_step_dual")) return rc; attr = true; }
   hipLaunchKernelGGL(gru_step2_dual_kernel, dim3(2 * nb), dim3(4 * WAVE), bytes, as_stream(stream), a, c, nb);
   MAPPO_CHECK_LAUNCH("gru_step_dual");
+  return MAPPO_OK;
+}
+
+// One rollout step of a recurrent actor and critic with narrow inputs, trunk included: obs / share_obs rows -> actions, log-probs,
+// values, next states (r_actor_critic.py:43-70,146-165 for both networks on the same rows).
+extern "C" int mappo_recurrent_step_dual(const float *actor_params, const mappo_net_desc *actor_desc, const float *obs,
+                                         const float *actor_h0, float *actor_h_last, const float *critic_params,
+                                         const mappo_net_desc *critic_desc, const float *share_obs, const float *critic_h0,
+                                         float *critic_h_last, const float *masks, int32_t Nc, const float *avail, int32_t deterministic,
+                                         uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions, float *logp,
+                                         float *values, mappo_stream_t stream) {
+  if (int rc = check_rec(actor_desc, "recurrent_step_dual")) return rc;
+  if (int rc = check_rec(critic_desc, "recurrent_step_dual")) return rc;
+  MAPPO_REQUIRE(critic_desc->out_dim == 1, "recurrent_step_dual: critic out_dim must be 1");
+  MAPPO_REQUIRE(actor_desc->in_dim <= 64 && critic_desc->in_dim <= 64, "recurrent_step_dual: in_dim <= 64 (wider inputs: mlp_features_dual + gru_step_dual)");
+  MAPPO_REQUIRE(actor_desc->layer_N == critic_desc->layer_N && actor_desc->use_relu == critic_desc->use_relu && actor_desc->layer_N <= 1,
+                "recurrent_step_dual: the networks must share layer_N (<= 1: two hidden layers do not fit the register file) and the activation");
+  MAPPO_REQUIRE(actor_params && obs && actor_h0 && critic_params && share_obs && critic_h0 && masks && actions && logp && values && Nc > 0,
+                "recurrent_step_dual: bad arguments");
+  MAPPO_CLEAR_STICKY();
+  GruFwdArgs a = {}, c = {};
+  a.params = actor_params; a.off = net_offsets(*actor_desc); a.x_rows = obs; a.desc = *actor_desc; a.h0 = actor_h0; a.masks = masks; a.L = 1; a.Nc = Nc;
+  a.A = actor_desc->out_dim; a.head_mode = 2; a.h_last = actor_h_last; a.avail = avail; a.actions = actions; a.logp = logp;
+  a.deterministic = deterministic; a.seed = seed; a.counter = counter; a.counter_dev = counter_dev;
+  c.params = critic_params; c.off = net_offsets(*critic_desc); c.x_rows = share_obs; c.desc = *critic_desc; c.h0 = critic_h0; c.masks = masks; c.L = 1; c.Nc = Nc;
+  c.A = 1; c.head_mode = 1; c.h_last = critic_h_last; c.out = values;
+  const int nt16 = (Nc + 15) / 16;
+  const int g3 = nt16 < NUM_CU ? nt16 : NUM_CU;
+  const dim3 grid(2 * g3), block(4 * WAVE);
+  hipStream_t st = as_stream(stream);
+  const bool relu = actor_desc->use_relu != 0;
+  switch (actor_desc->layer_N) {
+    case 0: if (relu) hipLaunchKernelGGL((gru_step3f_dual_kernel<1, 0>), grid, block, 0, st, a, c, g3); else hipLaunchKernelGGL((gru_step3f_dual_kernel<2, 0>), grid, block, 0, st, a, c, g3); break;
+    default: if (relu) hipLaunchKernelGGL((gru_step3f_dual_kernel<1, 1>), grid, block, 0, st, a, c, g3); else hipLaunchKernelGGL((gru_step3f_dual_kernel<2, 1>), grid, block, 0, st, a, c, g3); break;
+  }
+  MAPPO_CHECK_LAUNCH("recurrent_step_dual");
   return MAPPO_OK;
 }
 

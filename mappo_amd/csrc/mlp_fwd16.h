@@ -14,11 +14,7 @@
 // Same arithmetic as mlp_forward_kernel up to the order of the fp32 sums.
 #pragma once
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-
-__device__ __forceinline__ float quad_sum16(float v) { return xhalf_sum(xrow_sum(v)); }     // lanes j, j+16, j+32, j+48
+#include "mlp_trunk16r.h"
 
 // act + LayerNorm(64) of acc[b][r] (feature 16 b + 4 q + r) -> h = xhat * gamma + beta (the next layer's B operands)
 template <bool RELU>
@@ -133,75 +129,21 @@ __device__ __forceinline__ void forward16_tail(const FwdArgs &p, float *lds, con
 // no LDS except the logits tile of the sampling epilogue.  k-step (b, i) takes input / hidden feature 16 b + 4 q + i in every
 // layer.  (Rows of W1 are read up to 15 floats past in_dim — into the next row or the bias that follows W1 in the flat
 // parameter vector: finite values that meet zero inputs.)
-typedef float f32x4_ua __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ f32x4 ld4ua(const float *p) { const f32x4_ua v = *reinterpret_cast<const f32x4_ua *>(p); f32x4 r; r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3]; return r; }
-
-// act + LayerNorm(64) with the affine in registers (g, t: features 16 b + 4 q + r of gamma / beta)
-template <bool RELU>
-__device__ __forceinline__ void act_ln16r(f32x4 (&acc)[4], const f32x4 (&g)[4], const f32x4 (&t)[4]) {
-  float s = 0.f;
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { acc[b][r] = act_fwd<RELU>(acc[b][r]); s += acc[b][r]; }
-  const float mean = quad_sum16(s) * (1.f / HID);
-  float v = 0.f;
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const float c = acc[b][r] - mean; v += c * c; }
-  const float rstd = 1.0f / sqrtf(quad_sum16(v) * (1.f / HID) + LN_EPS);
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[b][r] = (acc[b][r] - mean) * rstd * g[b][r] + t[b][r];
-}
-
 template <bool RELU, int LN, int MODE>
 __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, const int bid, const int nb) {
   const int n_waves = blockDim.x / WAVE;
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), j = lane & 15, q = lane >> 4;
   const int D = p.desc.in_dim, A = p.desc.out_dim;
-  const int NB1 = (D + 15) >> 4;                                 // 16-wide k-blocks of the input layer
   const int64_t n_tiles = (p.B + 15) / 16;
   const bool fnorm = p.desc.use_feature_norm != 0;
-  const float inv_D = 1.0f / (float)D;
   float *tZ = lds + wave * 16 * TP;                              // [16][TP] logits of this wave's samples (MODE 1)
   int64_t tile = (int64_t)bid * n_waves + wave;
   if (tile >= n_tiles) return;
   const float *P = p.params;
   // ---- weights and vectors of this lane (issued before the first wait) ----
-  f32x4 w1[4][4];                                                // [bo][b]: W1[16 bo + j][16 b + 4 q ..]
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-    if (b < NB1) {
-#pragma unroll
-      for (int bo = 0; bo < 4; ++bo) w1[bo][b] = ld4ua(P + o.w1 + (size_t)(16 * bo + j) * D + 16 * b + 4 * q);
-    }
-  f32x4 g0[4], t0[4];                                            // feature-norm affine of the inputs (zero beyond in_dim)
-#pragma unroll
-  for (int b = 0; b < 4; ++b)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k = 16 * b + 4 * q + r;
-      const bool in = fnorm && k < D;
-      const float gv = P[o.fn_w + min(k, D - 1)], tv = P[o.fn_b + min(k, D - 1)];
-      g0[b][r] = in ? gv : ((!fnorm && k < D) ? 1.f : 0.f);
-      t0[b][r] = in ? tv : 0.f;
-    }
-  f32x4 b1v[4], g1[4], t1[4];
-#pragma unroll
-  for (int b = 0; b < 4; ++b) { b1v[b] = ld4ua(P + o.b1 + 16 * b + 4 * q); g1[b] = ld4ua(P + o.ln1_w + 16 * b + 4 * q); t1[b] = ld4ua(P + o.ln1_b + 16 * b + 4 * q); }
-  f32x4 w2[LN > 0 ? LN : 1][4][4], b2v[LN > 0 ? LN : 1][4], g2[LN > 0 ? LN : 1][4], t2[LN > 0 ? LN : 1][4];
-#pragma unroll
-  for (int l = 0; l < LN; ++l)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-#pragma unroll
-      for (int bo = 0; bo < 4; ++bo) w2[l][bo][b] = ld4ua(P + o.w2[l] + (size_t)(16 * bo + j) * HID + 16 * b + 4 * q);
-      b2v[l][b] = ld4ua(P + o.b2[l] + 16 * b + 4 * q); g2[l][b] = ld4ua(P + o.ln2_w[l] + 16 * b + 4 * q); t2[l][b] = ld4ua(P + o.ln2_b[l] + 16 * b + 4 * q);
-    }
+  Trunk16R<LN> tw;
+  trunk16r_load<LN>(tw, P, o, p.desc, j, q);
   constexpr int NBH = MODE == 1 ? 2 : (MODE == 0 ? 1 : 0);       // head blocks of 16 outputs (critic: row 0 only)
   f32x4 wh[NBH > 0 ? NBH : 1][4];
   f32x4 bhv[NBH > 0 ? NBH : 1];
@@ -228,54 +170,8 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
     for (int b = 0; b < 4; ++b)
 #pragma unroll
       for (int r = 0; r < 4; ++r) x[b][r] = p.x[off + min(16 * b + 4 * q + r, D - 1)];
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x[b][r] = (ok && 16 * b + 4 * q + r < D) ? x[b][r] : 0.f;
-    if (fnorm) {
-      float s = 0.f;
-#pragma unroll
-      for (int b = 0; b < 4; ++b) s += (x[b][0] + x[b][1]) + (x[b][2] + x[b][3]);
-      const float mean = quad_sum16(s) * inv_D;
-      float v = 0.f;
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { const float c = (16 * b + 4 * q + r < D) ? x[b][r] - mean : 0.f; x[b][r] = c; v += c * c; }
-      const float rstd = 1.0f / sqrtf(quad_sum16(v) * inv_D + LN_EPS);
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) x[b][r] = x[b][r] * rstd * g0[b][r] + t0[b][r];
-    }
-    // ---- layer 1 ----
     f32x4 h[4];
-#pragma unroll
-    for (int bo = 0; bo < 4; ++bo) h[bo] = b1v[bo];
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-      if (b < NB1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int bo = 0; bo < 4; ++bo) h[bo] = mfma16(w1[bo][b][r], x[b][r], h[bo]);
-      }
-    act_ln16r<RELU>(h, g1, t1);
-#pragma unroll
-    for (int l = 0; l < LN; ++l) {
-      f32x4 h2[4];
-#pragma unroll
-      for (int bo = 0; bo < 4; ++bo) h2[bo] = b2v[l][bo];
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int bo = 0; bo < 4; ++bo) h2[bo] = mfma16(w2[l][bo][b][r], h[b][r], h2[bo]);
-      act_ln16r<RELU>(h2, g2[l], t2[l]);
-#pragma unroll
-      for (int b = 0; b < 4; ++b) h[b] = h2[b];
-    }
+    trunk16r_apply<RELU, LN>(tw, x, h, D, ok, fnorm, q);
     // ---- head ----
     if constexpr (MODE == 2) {
       if (ok) {

@@ -372,6 +372,17 @@ def gru_step_dual(actor_params, actor_desc, actor_featT, actor_h0, actor_h_last,
     _lib.check(rc, "mappo_gru_step_dual")
 
 
+def recurrent_step_dual(actor_params, actor_desc, actor_obs, actor_h0, actor_h_last, critic_params, critic_desc, critic_obs, critic_h0,
+                  critic_h_last, masks, Nc, avail, deterministic, seed, counter, counter_dev, actions, logp, values):
+    """One rollout step of a recurrent actor and critic in ONE launch (mappo_recurrent_step_dual)."""
+    rc = _lib.load().mappo_recurrent_step_dual(_ptr(actor_params), C.byref(actor_desc), _ptr(actor_obs), _ptr(actor_h0), _ptr(actor_h_last),
+                                         _ptr(critic_params), C.byref(critic_desc), _ptr(critic_obs), _ptr(critic_h0),
+                                         _ptr(critic_h_last), _ptr(masks), int(Nc), _ptr(avail, allow_none=True), int(bool(deterministic)),
+                                         int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
+                                         _ptr(counter_dev, torch.int64, allow_none=True), _ptr(actions), _ptr(logp), _ptr(values), _stream())
+    _lib.check(rc, "mappo_recurrent_step_dual")
+
+
 def mlp_features_dual(params_a, desc_a, x_a, featT_a, params_c, desc_c, x_c, featT_c, B):
     """Trunk features of two networks on the same B rows in one launch (in_dim <= 64, same layer_N / activation)."""
     rc = _lib.load().mappo_mlp_features_dual(_ptr(params_a), C.byref(desc_a), _ptr(x_a), _ptr(featT_a), _ptr(params_c), C.byref(desc_c),
