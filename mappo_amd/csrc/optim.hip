@@ -24,51 +24,56 @@ __device__ __forceinline__ int seg_of(const SegBounds &sb, int64_t i) {
   return s;
 }
 
-// grad[p] = sum over slabs (per-workgroup partial gradients written by the update kernels); coalesced in p,
-// 16 independent loads in flight per thread (the pass is a pure HBM/L2 stream: n_slabs * P * 4 bytes).
+// grad[p] = sum over slabs (per-workgroup partial gradients written by the update kernels); coalesced in p.  A workgroup owns
+// 128 parameters and splits the slab rows in four: quarter q (two waves) sums rows [q n / 4, (q + 1) n / 4) with 16 independent
+// loads in flight per thread, the quarters meet in LDS in a fixed order (deterministic).  One thread per parameter walked the
+// 256 rows as 16 dependent batches — a latency chain of 6.5 us per PPO epoch for a pass that moves 7 MB.
 #define SLAB_BLOCK 128
-__global__ __launch_bounds__(SLAB_BLOCK) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs,
-                                                                int64_t stride, int64_t P, float *__restrict__ grad) {
-  const int64_t p = (int64_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
-  if (p >= P) return;
+#define SLAB_Q 4
+__device__ __forceinline__ float slab_quarter_sum(const float *__restrict__ slabs, int n_slabs, int64_t stride, int64_t p, int quarter) {
+  const int s_hi = (int)(((int64_t)(quarter + 1) * n_slabs) / SLAB_Q);
+  int s = (int)(((int64_t)quarter * n_slabs) / SLAB_Q);
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  int s = 0;
-  for (; s + 16 <= n_slabs; s += 16) {
+  for (; s + 16 <= s_hi; s += 16) {
     float v[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = slabs[(size_t)(s + j) * stride + p];
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j & 3] += v[j];          // fixed association: deterministic
   }
-  for (; s < n_slabs; ++s) acc[0] += slabs[(size_t)s * stride + p];
-  grad[p] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+  for (; s < s_hi; ++s) acc[0] += slabs[(size_t)s * stride + p];
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+// the workgroup's 128 sums: valid in the threads of quarter 0 (threadIdx.x < 128), 0 elsewhere
+__device__ __forceinline__ float slab_block_sum(const float *__restrict__ slabs, int n_slabs, int64_t stride, int64_t P, int64_t &p_out) {
+  __shared__ float sq[SLAB_Q][SLAB_BLOCK];
+  const int pi = threadIdx.x & (SLAB_BLOCK - 1), quarter = threadIdx.x / SLAB_BLOCK;
+  const int64_t p = (int64_t)blockIdx.x * SLAB_BLOCK + pi;
+  p_out = p;
+  sq[quarter][pi] = p < P ? slab_quarter_sum(slabs, n_slabs, stride, p, quarter) : 0.f;
+  __syncthreads();
+  return quarter == 0 ? (sq[0][pi] + sq[1][pi]) + (sq[2][pi] + sq[3][pi]) : 0.f;
+}
+
+__global__ __launch_bounds__(SLAB_BLOCK * SLAB_Q) void slab_reduce_kernel(const float *__restrict__ slabs, int n_slabs,
+                                                                         int64_t stride, int64_t P, float *__restrict__ grad) {
+  int64_t p;
+  const float g = slab_block_sum(slabs, n_slabs, stride, P, p);
+  if (threadIdx.x < SLAB_BLOCK && p < P) grad[p] = g;
 }
 
 // ---- two-launch variant of slab_reduce + clip_adam (the per-update tail of the PPO loop is launch-bound: every
 // kernel here runs a few microseconds, so the launches themselves are what it costs) --------------------------------
 // (1) slab_reduce that also leaves the squared-norm partial of its 128 gradient entries;
 // (2) norm finalisation + Adam in one kernel (see norm_adam_kernel).
-__global__ __launch_bounds__(SLAB_BLOCK) void slab_reduce_sq_kernel(const float *__restrict__ slabs, int n_slabs, int64_t stride,
-                                                                   int64_t P, float *__restrict__ grad, double *__restrict__ partials,
-                                                                   const float *__restrict__ hyper, int32_t *step, int n_seg) {
+__global__ __launch_bounds__(SLAB_BLOCK * SLAB_Q) void slab_reduce_sq_kernel(const float *__restrict__ slabs, int n_slabs, int64_t stride,
+                                                                            int64_t P, float *__restrict__ grad, double *__restrict__ partials,
+                                                                            const float *__restrict__ hyper, int32_t *step, int n_seg) {
   __shared__ double smem[16];
   if (blockIdx.x == 0 && threadIdx.x < n_seg && hyper[threadIdx.x * 8 + 7] != 0.f) step[threadIdx.x] += 1;   // Adam step of enabled segments
-  const int64_t p = (int64_t)blockIdx.x * SLAB_BLOCK + threadIdx.x;
-  float g = 0.f;
-  if (p < P) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    int s = 0;
-    for (; s + 16 <= n_slabs; s += 16) {
-      float v[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = slabs[(size_t)(s + j) * stride + p];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j & 3] += v[j];          // same association as slab_reduce_kernel
-    }
-    for (; s < n_slabs; ++s) acc[0] += slabs[(size_t)s * stride + p];
-    g = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    grad[p] = g;
-  }
+  int64_t p;
+  const float g = slab_block_sum(slabs, n_slabs, stride, P, p);         // (0 in the threads of quarters 1..3)
+  if (threadIdx.x < SLAB_BLOCK && p < P) grad[p] = g;
   double v[1] = {(double)g * (double)g};
   block_sum<1>(v, smem);
   if (threadIdx.x == 0) partials[blockIdx.x] = v[0];
@@ -152,7 +157,7 @@ extern "C" int mappo_slab_reduce(const float *slabs, int32_t n_slabs, int64_t sl
                                  mappo_stream_t stream) {
   MAPPO_REQUIRE(slabs && grad && n_slabs > 0 && P > 0 && slab_stride >= P, "slab_reduce: bad arguments");
   const int nblk = (int)((P + SLAB_BLOCK - 1) / SLAB_BLOCK);
-  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_kernel, dim3(nblk), dim3(SLAB_BLOCK), 0, as_stream(stream), slabs,
+  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_kernel, dim3(nblk), dim3(SLAB_BLOCK * SLAB_Q), 0, as_stream(stream), slabs,
               (int)n_slabs, slab_stride, P, grad);
   MAPPO_CHECK_LAUNCH("slab_reduce");
   return MAPPO_OK;
@@ -206,7 +211,7 @@ extern "C" int mappo_reduce_clip_adam(const float *slabs, int32_t n_slabs, int64
   const int nblk = (int)(P / SLAB_BLOCK);             // P is a multiple of 256: mappo_optim_workspace_bytes(P) covers P/128 doubles
   double *partials = (double *)workspace;
   hipStream_t st = as_stream(stream);
-  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_sq_kernel, dim3(nblk), dim3(SLAB_BLOCK), 0, st, slabs, (int)n_slabs, slab_stride, P,
+  PROF_LAUNCH(MAPPO_PROF_SLAB_REDUCE, slab_reduce_sq_kernel, dim3(nblk), dim3(SLAB_BLOCK * SLAB_Q), 0, st, slabs, (int)n_slabs, slab_stride, P,
               grad, partials, opt_hyper, opt_step, (int)n_seg);
   PROF_LAUNCH(MAPPO_PROF_ADAM, norm_adam_kernel, dim3((unsigned)(P / OPT_BLOCK)), dim3(OPT_BLOCK), 0, st, (const double *)partials, sb,
               opt_hyper, (const int32_t *)opt_step, grad_norms, norm_acc, params, (const float *)grad, exp_avg, exp_avg_sq);
