@@ -1286,7 +1286,7 @@ __global__ __launch_bounds__(UPD_THREADS, 1) void mlp_update_kernel(UpdArgs p) {
 #include "mlp_upd2.h"
 #include "mlp_upd16.h"
 #include "mlp_wide16_args.h"
-#ifdef MLP_TU_WIDE
+#if defined(MLP_TU_WIDE) || defined(MLP_TU_WIDE_FWD) || defined(MLP_TU_WIDE_SK)
 #include "mlp_wide16.h"
 #endif
 
@@ -1297,6 +1297,12 @@ int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, di
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st);
 int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa,
                                 const FwdArgs &a, const Wide16Args &wc, const FwdArgs &c, int nA);
+template <bool R>
+int wide16_launch_forward_r(int mode, int ln, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a,
+                            const char *who);
+template <bool R>
+int wide16_launch_features_dual_r(int ln, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                  const Wide16Args &wc, const FwdArgs &c, int nA);
 // split-K variants (one tile per 4-wave workgroup): step-sized batches
 int wide16_launch_forward_sk(int mode, bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a,
                              const char *who);
@@ -1325,61 +1331,68 @@ int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
   return wide16_l1_fwd_one<8>(w, grid, lds_bytes, st);
 }
 
-template <bool R, int L, int MODE, int NWV, int NCH>
+#endif
+
+#ifdef MLP_TU_WIDE_FWD
+// compiled once per activation (mlp_wide_fwd_r{0,1}.hip: MLP_WIDE_RELU); 8-wave workgroups only — batches of up to 256 tiles take
+// the split-K kernels, and above that the 8-wave groups have enough tiles
+template <bool R, int L, int MODE, int NCH>
 static int wide16_forward_one(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE, NWV, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE, 8, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
     if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
     attr_set = true;
   }
   const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
-  PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE, NWV, NCH>), grid, block, lds_bytes, st, w, a);
+  PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE, 8, NCH>), grid, block, lds_bytes, st, w, a);
   return MAPPO_OK;
 }
 template <bool R, int L, int MODE>
-static int wide16_forward_nw(bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
-  const bool half = w.D <= 256;                               // row block registers for 4 chunks instead of 8
-  if (small) return half ? wide16_forward_one<R, L, MODE, 4, 4>(grid, block, lds_bytes, st, w, a, who) : wide16_forward_one<R, L, MODE, 4, 8>(grid, block, lds_bytes, st, w, a, who);
-  return half ? wide16_forward_one<R, L, MODE, 8, 4>(grid, block, lds_bytes, st, w, a, who) : wide16_forward_one<R, L, MODE, 8, 8>(grid, block, lds_bytes, st, w, a, who);
+static int wide16_forward_nch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
+  return w.D <= 256 ? wide16_forward_one<R, L, MODE, 4>(grid, block, lds_bytes, st, w, a, who)       // row block registers for 4 chunks instead of 8
+                    : wide16_forward_one<R, L, MODE, 8>(grid, block, lds_bytes, st, w, a, who);
 }
 template <bool R, int L>
-static int wide16_forward_mode(int mode, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
-  if (mode == 0) return wide16_forward_nw<R, L, 0>(small, grid, block, lds_bytes, st, w, a, who);
-  if (mode == 1) return wide16_forward_nw<R, L, 1>(small, grid, block, lds_bytes, st, w, a, who);
-  return wide16_forward_nw<R, L, 2>(small, grid, block, lds_bytes, st, w, a, who);
+static int wide16_forward_mode(int mode, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
+  if (mode == 0) return wide16_forward_nch<R, L, 0>(grid, block, lds_bytes, st, w, a, who);
+  if (mode == 1) return wide16_forward_nch<R, L, 1>(grid, block, lds_bytes, st, w, a, who);
+  return wide16_forward_nch<R, L, 2>(grid, block, lds_bytes, st, w, a, who);
 }
-int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
-                          const Wide16Args &w, const FwdArgs &a, const char *who) {
-  if (ln == 0) return relu ? wide16_forward_mode<true, 0>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 0>(mode, small, grid, block, lds_bytes, st, w, a, who);
-  if (ln == 1) return relu ? wide16_forward_mode<true, 1>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 1>(mode, small, grid, block, lds_bytes, st, w, a, who);
-  return relu ? wide16_forward_mode<true, 2>(mode, small, grid, block, lds_bytes, st, w, a, who) : wide16_forward_mode<false, 2>(mode, small, grid, block, lds_bytes, st, w, a, who);
+template <bool R>
+int wide16_launch_forward_r(int mode, int ln, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a,
+                            const char *who) {
+  if (ln == 0) return wide16_forward_mode<R, 0>(mode, grid, block, lds_bytes, st, w, a, who);
+  if (ln == 1) return wide16_forward_mode<R, 1>(mode, grid, block, lds_bytes, st, w, a, who);
+  return wide16_forward_mode<R, 2>(mode, grid, block, lds_bytes, st, w, a, who);
 }
+template int wide16_launch_forward_r<MLP_WIDE_RELU>(int, int, dim3, dim3, size_t, hipStream_t, const Wide16Args &, const FwdArgs &, const char *);
 
-template <bool R, int L, int NWV>
+template <bool R, int L>
 static int wide16_features_dual_one(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const WideDualArgs &d) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_dual_kernel<R, L, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+    hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_dual_kernel<R, L, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
     if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
     attr_set = true;
   }
-  PROF_LAUNCH(MAPPO_PROF_MLP_FWD, (wide_features16_dual_kernel<R, L, NWV>), grid, block, lds_bytes, st, d);
+  PROF_LAUNCH(MAPPO_PROF_MLP_FWD, (wide_features16_dual_kernel<R, L, 8>), grid, block, lds_bytes, st, d);
   return MAPPO_OK;
 }
-template <bool R, int L>
-static int wide16_features_dual_nw(bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const WideDualArgs &d) {
-  return small ? wide16_features_dual_one<R, L, 4>(grid, block, lds_bytes, st, d) : wide16_features_dual_one<R, L, 8>(grid, block, lds_bytes, st, d);
-}
-int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa,
-                                const FwdArgs &a, const Wide16Args &wc, const FwdArgs &c, int nA) {
+template <bool R>
+int wide16_launch_features_dual_r(int ln, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                  const Wide16Args &wc, const FwdArgs &c, int nA) {
   WideDualArgs d;
   d.wa = wa; d.wc = wc; d.a = a; d.c = c; d.nA = nA;
-  if (ln == 0) return relu ? wide16_features_dual_nw<true, 0>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 0>(small, grid, block, lds_bytes, st, d);
-  if (ln == 1) return relu ? wide16_features_dual_nw<true, 1>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 1>(small, grid, block, lds_bytes, st, d);
-  return relu ? wide16_features_dual_nw<true, 2>(small, grid, block, lds_bytes, st, d) : wide16_features_dual_nw<false, 2>(small, grid, block, lds_bytes, st, d);
+  if (ln == 0) return wide16_features_dual_one<R, 0>(grid, block, lds_bytes, st, d);
+  if (ln == 1) return wide16_features_dual_one<R, 1>(grid, block, lds_bytes, st, d);
+  return wide16_features_dual_one<R, 2>(grid, block, lds_bytes, st, d);
 }
+template int wide16_launch_features_dual_r<MLP_WIDE_RELU>(int, dim3, dim3, size_t, hipStream_t, const Wide16Args &, const FwdArgs &,
+                                                          const Wide16Args &, const FwdArgs &, int);
+#endif
 
+#ifdef MLP_TU_WIDE_SK
 template <bool R, int L, int MODE>
 static int wide16_forward_sk_one(dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
   static bool attr_set = false;
@@ -1422,6 +1435,22 @@ int wide16_launch_features_sk_dual(bool relu, int ln, dim3 grid, size_t lds_byte
   if (ln == 0) return relu ? wide16_features_sk_dual_one<true, 0>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 0>(grid, lds_bytes, st, d);
   if (ln == 1) return relu ? wide16_features_sk_dual_one<true, 1>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 1>(grid, lds_bytes, st, d);
   return relu ? wide16_features_sk_dual_one<true, 2>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 2>(grid, lds_bytes, st, d);
+}
+
+#endif
+
+#ifdef MLP_TU_WIDE
+int wide16_launch_forward(int mode, bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st,
+                          const Wide16Args &w, const FwdArgs &a, const char *who) {
+  (void)small;
+  return relu ? wide16_launch_forward_r<true>(mode, ln, grid, block, lds_bytes, st, w, a, who)
+              : wide16_launch_forward_r<false>(mode, ln, grid, block, lds_bytes, st, w, a, who);
+}
+int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa,
+                                const FwdArgs &a, const Wide16Args &wc, const FwdArgs &c, int nA) {
+  (void)small;
+  return relu ? wide16_launch_features_dual_r<true>(ln, grid, block, lds_bytes, st, wa, a, wc, c, nA)
+              : wide16_launch_features_dual_r<false>(ln, grid, block, lds_bytes, st, wa, a, wc, c, nA);
 }
 
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st) {
@@ -1596,13 +1625,12 @@ static int wide_forward_prepare(FwdArgs &a, Wide16Args &w, size_t &lb, dim3 &gri
   w = Wide16Args{};
   w.params = a.params; w.x = a.x; w.rows = a.rows; w.B = a.B; w.D = a.desc.in_dim; w.w1 = a.off.w1; w.b1 = a.off.b1;
   w.fn_w = a.desc.use_feature_norm ? a.off.fn_w : -1; w.fn_b = a.desc.use_feature_norm ? a.off.fn_b : -1;
-  // rollout-sized batches: 4-wave workgroups (twice the workgroups, one wave per SIMD) until 8-wave groups fill the chip
+  // 8 tiles (one per wave) share the weight stream; at most one workgroup per CU
   const int64_t n_tiles16 = (a.B + 15) / 16;
-  small = n_tiles16 < 8 * (int64_t)NUM_CU;
-  const int64_t n_groups = small ? (n_tiles16 + 3) / 4 : (n_tiles16 + 7) / 8;
-  const int64_t cap = small ? 2 * NUM_CU : NUM_CU;
-  grid = dim3((unsigned)(n_groups < cap ? n_groups : cap));
-  block = dim3(small ? 256 : 512);
+  small = false;                                               // (4-wave groups went away with the split-K kernels for <= 256 tiles)
+  const int64_t n_groups = (n_tiles16 + 7) / 8;
+  grid = dim3((unsigned)(n_groups < NUM_CU ? n_groups : NUM_CU));
+  block = dim3(512);
   return MAPPO_OK;
 }
 
