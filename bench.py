@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — agent-steps/sec of one full MAPPO iteration (collect + GAE + PPO) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`,
+WORLD_SIZE set) this process is one of the ranks; started bare (`python bench.py --gpus N`) it spawns that launcher itself as a
+child process and relays rank 0's JSON line (launch_ranks).
 
 A "step" is one training iteration of BASELINE.json configs[1]: episode_length=25 rollout steps over
 n_rollout_threads=1024 (--scaling strong, the default: 1024 threads IN TOTAL, sharded over the ranks as north_star and
@@ -139,6 +143,8 @@ def parse():
     ap.add_argument("--exact_minibatch_order", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_threads", type=int, default=0, help="0 = all cores of this box (max 16)")
+    ap.add_argument("--dry_launch", action="store_true",
+                    help="launcher rehearsal without a GPU: every rank prints its RANK / WORLD_SIZE / LOCAL_RANK and exits (CPU test of --gpus N)")
     ns = ap.parse_args()
     dflt = dict(c2=(1024, 25, 10, 1), c4=(512, 400, 5, 2))[ns.config]
     for k, v in zip(("n_rollout_threads", "episode_length", "ppo_epoch", "num_mini_batch"), dflt):
@@ -308,7 +314,7 @@ def main_c4(ns, world, rank, device, result_out, force_dp):
                                     f"ppo_epoch={a.ppo_epoch}, num_mini_batch={a.num_mini_batch}, lr 5e-4",
                            n_rollout_threads_global=ns.global_threads, n_rollout_threads_rank0=a.n_rollout_threads, episode_length=a.episode_length,
                            num_agents=M, ppo_epoch=a.ppo_epoch, num_mini_batch=a.num_mini_batch, agent_steps_per_step=global_steps,
-                           parallelism=f"dp{world}"),
+                           parallelism=f"dp{world}", rccl_ranks=ns.rccl_ranks),
                roofline=None, cpu_baseline=None,
                note="secondary configuration (SURVEY 8e strong-scaling shape); the roofline / cpu_baseline objects belong to the default --config c2 line",
                last_train_info={k: float(v) for k, v in info.items()})
@@ -320,10 +326,54 @@ def main_c4(ns, world, rank, device, result_out, force_dp):
         dist.destroy_process_group()
 
 
+def launch_ranks(ns):
+    """`python bench.py --gpus N` without a launcher around it: this process — which has made NO GPU call (importing torch
+    and counting devices does not initialise HIP) — starts `python -m torch.distributed.run` with N ranks of this same script as
+    a CHILD process (never an exec: a process that touched the GPU must not be replaced), relays rank 0's single JSON line
+    and exits with the child's code."""
+    import socket
+    import subprocess
+    if not ns.dry_launch:
+        n_dev = torch.cuda.device_count()
+        if n_dev < ns.gpus:
+            print(f"bench.py: --gpus {ns.gpus} but only {n_dev} GPU(s) visible on this node", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ns.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    if ns.dry_launch:
+        for ln in sorted(lines):
+            print(ln, flush=True)
+        return proc.returncode
+    result = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if ln not in result:
+            print(ln, file=sys.stderr)                          # anything else a rank wrote to stdout is not the result line
+    if proc.returncode != 0 or len(result) != 1:
+        print(f"bench.py: {ns.gpus}-rank run failed (exit code {proc.returncode}, {len(result)} result lines)", file=sys.stderr)
+        return proc.returncode or 1
+    print(result[0], flush=True)
+    return 0
+
+
 def main():
     ns = parse()
+    if ns.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(ns))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    if ns.gpus > 1 and world != ns.gpus:
+        sys.exit(f"bench.py: --gpus {ns.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if ns.dry_launch:
+        print(json.dumps(dict(rank=rank, world=world, local_rank=int(os.environ.get("LOCAL_RANK", "0")), gpus=ns.gpus)), flush=True)
+        return
     from mappo_amd.distributed import shard_threads
     if ns.scaling == "strong":                              # global thread count fixed: this rank's contiguous share
         lo, hi = shard_threads(ns.n_rollout_threads, rank, world)
@@ -345,8 +395,12 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world and (ns.gpus <= 1 or dist.get_world_size() == ns.gpus), \
+            f"process group has {dist.get_world_size()} ranks, expected {max(ns.gpus, world)}"
+        ns.rccl_ranks = dist.get_world_size()
     else:
         torch.cuda.set_device(0)
+        ns.rccl_ranks = 0
     device = torch.device("cuda", torch.cuda.current_device())
 
     from mappo_amd.envs.synthetic import SyntheticMPEEnv
@@ -453,7 +507,7 @@ def main():
                            n_rollout_threads_global=ns.global_threads, n_rollout_threads_rank0=args.n_rollout_threads,
                            episode_length=args.episode_length,
                            num_agents=M, ppo_epoch=args.ppo_epoch, num_mini_batch=args.num_mini_batch,
-                           agent_steps_per_step=global_steps, parallelism=f"dp{world}",
+                           agent_steps_per_step=global_steps, parallelism=f"dp{world}", rccl_ranks=ns.rccl_ranks,
                            exact_minibatch_order=bool(args.exact_minibatch_order), hip_graph=bool(graph_flags[1])),
                roofline=roofline, ppo_loss_roofline=loss_roof, gae_roofline=gae_roof, kernels_us=kern, phase_ms=phase_ms,
                last_train_info={k: float(v) for k, v in info.items()})

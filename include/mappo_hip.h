@@ -201,13 +201,24 @@ int mappo_mlp_backward(const float *params, const mappo_net_desc *desc /*host*/,
                        float *slabs, int64_t slab_stride, int64_t slab_col0,
                        float *wide_ws /*in_dim > 64: mappo_wide_workspace_floats(B) floats, else NULL*/,
                        mappo_stream_t stream);
-/* Wide observations (64 < in_dim <= 512): the update / backward kernels run layer 1 K-chunked and leave d z1 plus the
- * per-row LayerNorm statistics in `wide_ws`; mappo_wide_l1_backward then produces the W1 and feature-norm gradient
- * columns (one slab row per workgroup of its grid.x, mappo_wide_l1_slabs(B) rows). */
+/* Wide observations (64 < in_dim <= 512; reference: mlp.py:18-55 with a wide input layer): the update / backward launches
+ * run layer 1 as their own MFMA kernel and leave d z1 plus the per-row LayerNorm statistics in `wide_ws`;
+ * mappo_wide_l1_backward then produces the W1 and feature-norm gradient columns (one slab row per workgroup of its grid.x,
+ * mappo_wide_l1_slabs(B) rows).  The workspace has one of two layouts, a PURE function of the descriptor and of which
+ * entry point filled it — mappo_wide_layout(desc, producer) — and the caller hands that value to mappo_wide_l1_backward:
+ * the library keeps no host-side record of workspaces (re-entrant per stream, safe across allocator address reuse). */
+#define MAPPO_WIDE_LAYOUT_FEATURE_MAJOR 0   /* dz1 [64][B] | mean0 [B] | rstd0 [B]                       (K-chunked kernels)   */
+#define MAPPO_WIDE_LAYOUT_BLOCKED 1         /* dz1 [tile][64][16] | padded statistics | z1 [B][64]        (16-sample-tile path) */
+#define MAPPO_PRODUCER_MLP_BACKWARD 0       /* mappo_mlp_backward   */
+#define MAPPO_PRODUCER_ACTOR_UPDATE 1       /* mappo_actor_update   */
+#define MAPPO_PRODUCER_CRITIC_UPDATE 2      /* mappo_critic_update  */
+#define MAPPO_PRODUCER_TRUNK_BACKWARD 3     /* mappo_trunk_backward */
 int64_t mappo_wide_workspace_floats(int64_t B);
 int32_t mappo_wide_l1_slabs(int64_t B);
+int32_t mappo_wide_layout(const mappo_net_desc *desc /*host*/, int32_t producer /*MAPPO_PRODUCER_**/); /* layout id, or MAPPO_EINVAL */
 int mappo_wide_l1_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x, const int32_t *rows,
                            int64_t B, const float *wide_ws, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                           int32_t layout /*mappo_wide_layout(desc, producer) of the launch that filled wide_ws*/,
                            mappo_stream_t stream);
 
 /* ---- fused update kernels (K7 + K5 + K7-backward in ONE launch per network; r_mappo.py:91-164) --------------

@@ -57,7 +57,8 @@ SIGNATURES = {
     "mappo_mlp_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _I64, _I64, _P, _P]),
     "mappo_wide_workspace_floats": (_I64, [_I64]),
     "mappo_wide_l1_slabs": (_I32, [_I64]),
-    "mappo_wide_l1_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _I64, _I64, _P]),
+    "mappo_wide_layout": (_I32, [C.POINTER(NetDesc), _I32]),
+    "mappo_wide_l1_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _I64, _I64, _I32, _P]),
     "mappo_update_partials_bytes": (_I64, []),
     "mappo_actor_update": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _P, _P, _P, _P, C.POINTER(PpoCfg), _P, _I64,
                                      _I64, _P, _P, _I32, _P]),

@@ -68,6 +68,11 @@ class R_MAPPO():
         self._dual_update = bool(getattr(args, "dual_update", True)) and os.environ.get("MAPPO_DUAL_UPDATE", "1") != "0"
         self._epochs = None                        # whole-buffer fused train(): per-epoch ValueNorm states + deferred statistics
         self._dist = dist_group                      # mappo_amd.distributed.DataParallel or None
+        if dist_group is not None:
+            # the actor keyed its sampling stream by the rank it saw at construction — rank 0 if the process group was created
+            # AFTER the policy; re-key from the group this trainer reduces over, so shards never share exploration noise
+            from mappo_amd.distributed import sampling_seed
+            policy.actor._seed = sampling_seed(int(getattr(args, "seed", 1)), dist_group.rank)
         f64 = dict(dtype=torch.float64, device=self.device)
         self._mb_moments = torch.zeros(4, **f64)
         self._adv_moments = torch.zeros(3, **f64)

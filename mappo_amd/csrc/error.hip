@@ -12,7 +12,7 @@ void mappo_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *mappo_last_error(void) { return g_err; }
-extern "C" int mappo_abi_version(void) { return 2; }
+extern "C" int mappo_abi_version(void) { return 3; }   // 3: mappo_wide_layout + explicit layout argument of mappo_wide_l1_backward
 
 ProfSlot g_prof[MAPPO_PROF_COUNT] = {};
 

@@ -1448,8 +1448,8 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   if (giT && head_mode == 0 && scratch) {                 // training pass: two waves per 32 sequences
     const SeqLds sm = seq2_lds(HID, 2);
     const size_t bytes = (size_t)sm.total * sizeof(float);
-    static bool attr2 = false;
-    if (!attr2) { if (int rc = raise_lds(gru_fwd_train2_kernel, "gru_forward")) return rc; attr2 = true; }
+    static const int lds_rc_attr2 = raise_lds(gru_fwd_train2_kernel, "gru_forward");
+    if (lds_rc_attr2) return lds_rc_attr2;
     hipLaunchKernelGGL(gru_fwd_train2_kernel, dim3(n_tiles < 4 * NUM_CU ? n_tiles : 4 * NUM_CU), dim3(2 * WAVE), bytes, as_stream(stream), a, sm);
     MAPPO_CHECK_LAUNCH("gru_forward");
     return MAPPO_OK;
@@ -1470,12 +1470,12 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
     int nb2 = (n_tiles + 1) / 2;
     if (nb2 > NUM_CU) nb2 = NUM_CU;
     if (head_mode == 1) {
-      static bool attr = false;
-      if (!attr) { if (int rc = raise_lds(gru_step2_kernel<1>, "gru_forward")) return rc; attr = true; }
+      static const int lds_rc_attr = raise_lds(gru_step2_kernel<1>, "gru_forward");
+      if (lds_rc_attr) return lds_rc_attr;
       hipLaunchKernelGGL(gru_step2_kernel<1>, dim3(nb2), dim3(4 * WAVE), bytes, as_stream(stream), a);
     } else {
-      static bool attr = false;
-      if (!attr) { if (int rc = raise_lds(gru_step2_kernel<2>, "gru_forward")) return rc; attr = true; }
+      static const int lds_rc_attr = raise_lds(gru_step2_kernel<2>, "gru_forward");
+      if (lds_rc_attr) return lds_rc_attr;
       hipLaunchKernelGGL(gru_step2_kernel<2>, dim3(nb2), dim3(4 * WAVE), bytes, as_stream(stream), a);
     }
     MAPPO_CHECK_LAUNCH("gru_forward");
@@ -1494,8 +1494,8 @@ extern "C" int mappo_gru_forward(const float *params, const mappo_net_desc *desc
   const int launch_waves = 4;
 #define GRU_FWD(PRE, HM_)                                                                                         \
   do {                                                                                                            \
-    static bool attr = false;                                                                                     \
-    if (!attr) { if (int rc = raise_lds(gru_fwd_kernel<PRE, HM_>, "gru_forward")) return rc; attr = true; }       \
+    static const int lds_rc_attr = raise_lds(gru_fwd_kernel<PRE, HM_>, "gru_forward");                                                                                     \
+    if (lds_rc_attr) return lds_rc_attr;       \
     hipLaunchKernelGGL((gru_fwd_kernel<PRE, HM_>), dim3(nb), dim3(WAVE * launch_waves), lds_bytes, as_stream(stream), a); \
   } while (0)
   if (giT) { if (head_mode == 0) GRU_FWD(true, 0); else if (head_mode == 1) GRU_FWD(true, 1); else GRU_FWD(true, 2); }
@@ -1539,8 +1539,8 @@ extern "C" int mappo_gru_step_dual(const float *actor_params, const mappo_net_de
   const int n_tiles = (Nc + TS - 1) / TS;
   int nb = (n_tiles + 1) / 2;
   if (nb > NUM_CU / 2) nb = NUM_CU / 2;
-  static bool attr = false;
-  if (!attr) { if (int rc = raise_lds(gru_step2_dual_kernel, "gru_step_dual")) return rc; attr = true; }
+  static const int lds_rc_attr = raise_lds(gru_step2_dual_kernel, "gru_step_dual");
+  if (lds_rc_attr) return lds_rc_attr;
   hipLaunchKernelGGL(gru_step2_dual_kernel, dim3(2 * nb), dim3(4 * WAVE), bytes, as_stream(stream), a, c, nb);
   MAPPO_CHECK_LAUNCH("gru_step_dual");
   return MAPPO_OK;
@@ -1628,19 +1628,19 @@ extern "C" int mappo_gru_backward(const float *params, const mappo_net_desc *des
     MAPPO_REQUIRE(hbytes <= LDS_DYN_MAX, "gru_backward: needs %zu B of LDS", hbytes);
     float *dhT = const_cast<float *>(scratch);
     if (head == 1) {
-      static bool attr = false;
-      if (!attr) { if (int rc = raise_lds(gru_head_bwd_kernel<1>, "gru_backward")) return rc; attr = true; }
+      static const int lds_rc_attr = raise_lds(gru_head_bwd_kernel<1>, "gru_backward");
+      if (lds_rc_attr) return lds_rc_attr;
       hipLaunchKernelGGL(gru_head_bwd_kernel<1>, dim3(nb), dim3(WAVE * nw), hbytes, as_stream(stream), a, dhT);
     } else {
-      static bool attr = false;
-      if (!attr) { if (int rc = raise_lds(gru_head_bwd_kernel<2>, "gru_backward")) return rc; attr = true; }
+      static const int lds_rc_attr = raise_lds(gru_head_bwd_kernel<2>, "gru_backward");
+      if (lds_rc_attr) return lds_rc_attr;
       hipLaunchKernelGGL(gru_head_bwd_kernel<2>, dim3(nb), dim3(WAVE * nw), hbytes, as_stream(stream), a, dhT);
     }
     MAPPO_CHECK_LAUNCH("gru_backward (head)");
     const SeqLds sm = seq2_lds(NG, 1);    // 75 KB: the actor's and the critic's workgroups share a CU
     const size_t sbytes = (size_t)sm.total * sizeof(float);
-    static bool attr2 = false;
-    if (!attr2) { if (int rc = raise_lds(gru_cell_bwd2_kernel, "gru_backward")) return rc; attr2 = true; }
+    static const int lds_rc_attr2 = raise_lds(gru_cell_bwd2_kernel, "gru_backward");
+    if (lds_rc_attr2) return lds_rc_attr2;
     hipLaunchKernelGGL(gru_cell_bwd2_kernel, dim3(n_ct < 4 * NUM_CU ? n_ct : 4 * NUM_CU), dim3(2 * WAVE), sbytes, as_stream(stream), a, sm);
     MAPPO_CHECK_LAUNCH("gru_backward (cell)");
   }
@@ -1664,8 +1664,8 @@ extern "C" int mappo_gru_wgrad(const mappo_net_desc *desc, const float *xT, cons
   a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
   MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru_wgrad: slab column range");
   const size_t lds_bytes = (size_t)4 * (96 + HID) * TP * sizeof(float);
-  static bool attr = false;
-  if (!attr) { if (int rc = raise_lds(gru_wgrad_kernel, "gru_wgrad")) return rc; attr = true; }
+  static const int lds_rc_attr = raise_lds(gru_wgrad_kernel, "gru_wgrad");
+  if (lds_rc_attr) return lds_rc_attr;
   const int nb = mappo_gru_wgrad_slabs(L, Nc);
   hipLaunchKernelGGL(gru_wgrad_kernel, dim3(nb), dim3(256), lds_bytes, as_stream(stream), a);
   MAPPO_CHECK_LAUNCH("gru_wgrad");
@@ -1684,12 +1684,12 @@ static int launch_gru_in(bool gates, const float *params, const mappo_net_desc *
   int64_t nb = (n_tiles + 3) / 4;
   if (nb > NUM_CU) nb = NUM_CU;
   if (gates) {
-    static bool attr = false;
-    if (!attr) { if (int rc = raise_lds(gru_gi_kernel, who)) return rc; attr = true; }
+    static const int lds_rc_attr = raise_lds(gru_gi_kernel, who);
+    if (lds_rc_attr) return lds_rc_attr;
     hipLaunchKernelGGL(gru_gi_kernel, dim3((unsigned)nb), dim3(256), lds_bytes, st, a);
   } else {
-    static bool attr = false;
-    if (!attr) { if (int rc = raise_lds(gru_dx_kernel, who)) return rc; attr = true; }
+    static const int lds_rc_attr = raise_lds(gru_dx_kernel, who);
+    if (lds_rc_attr) return lds_rc_attr;
     hipLaunchKernelGGL(gru_dx_kernel, dim3((unsigned)nb), dim3(256), lds_bytes, st, a);
   }
   MAPPO_CHECK_LAUNCH(who);

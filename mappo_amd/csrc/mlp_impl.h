@@ -36,8 +36,6 @@
 // Limits of this build: hidden == 64, out_dim <= 32, layer_N <= 2, in_dim <= 512.
 #include "mlp_core.h"
 #include <stdlib.h>
-#include <mutex>
-#include <unordered_map>
 
 #ifdef MLP_TU_MAIN
 extern "C" int64_t mappo_net_param_count(const mappo_net_desc *desc) {
@@ -1313,12 +1311,8 @@ int wide16_launch_features_sk_dual(bool relu, int ln, dim3 grid, size_t lds_byte
 #ifdef MLP_TU_WIDE
 template <int NCH>
 static int wide16_l1_fwd_one(const Wide16Args &w, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_fwd16_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
-    if (e_ != hipSuccess) { mappo_set_error("wide_l1_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_fwd16_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("wide_l1_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   hipLaunchKernelGGL((wide_l1_fwd16_kernel<NCH>), grid, dim3(512), lds_bytes, st, w);
   return MAPPO_OK;
 }
@@ -1338,12 +1332,8 @@ int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
 // the split-K kernels, and above that the 8-wave groups have enough tiles
 template <bool R, int L, int MODE, int NCH>
 static int wide16_forward_one(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE, 8, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
-    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_kernel<R, L, MODE, 8, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
   PROF_LAUNCH(pid, (wide_forward16_kernel<R, L, MODE, 8, NCH>), grid, block, lds_bytes, st, w, a);
   return MAPPO_OK;
@@ -1370,12 +1360,8 @@ template int wide16_launch_forward_r<MLP_WIDE_RELU>(int, int, dim3, dim3, size_t
 
 template <bool R, int L>
 static int wide16_features_dual_one(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const WideDualArgs &d) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_dual_kernel<R, L, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
-    if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_dual_kernel<R, L, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_FWD, (wide_features16_dual_kernel<R, L, 8>), grid, block, lds_bytes, st, d);
   return MAPPO_OK;
 }
@@ -1395,12 +1381,8 @@ template int wide16_launch_features_dual_r<MLP_WIDE_RELU>(int, dim3, dim3, size_
 #ifdef MLP_TU_WIDE_SK
 template <bool R, int L, int MODE>
 static int wide16_forward_sk_one(dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a, const char *who) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_sk_kernel<R, L, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
-    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_forward16_sk_kernel<R, L, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   const int pid = (MODE == 1) ? MAPPO_PROF_ACT : MAPPO_PROF_MLP_FWD;
   PROF_LAUNCH(pid, (wide_forward16_sk_kernel<R, L, MODE>), grid, dim3(256), lds_bytes, st, w, a);
   return MAPPO_OK;
@@ -1419,12 +1401,8 @@ int wide16_launch_forward_sk(int mode, bool relu, int ln, dim3 grid, size_t lds_
 }
 template <bool R, int L>
 static int wide16_features_sk_dual_one(dim3 grid, size_t lds_bytes, hipStream_t st, const WideDualArgs &d) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_sk_dual_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
-    if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_sk_dual_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_FWD, (wide_features16_sk_dual_kernel<R, L>), grid, dim3(256), lds_bytes, st, d);
   return MAPPO_OK;
 }
@@ -1490,13 +1468,9 @@ int upd16x_inst(int head, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t s
 #ifdef MLP_TU_UPD
 template <bool R, int L, int HEAD, int W>
 static int upd_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)LDS_DYN_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update_kernel<R, L, HEAD, W>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1514,13 +1488,9 @@ template int upd_inst<MLP_UPD_RELU, MLP_UPD_LN, 3>(int, dim3, dim3, size_t, hipS
 #ifdef MLP_TU_UPD2
 template <bool R, int L, int HEAD, bool W>
 static int upd2_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const UpdArgs &a, const char *who) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update2_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update2_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)LDS_DYN_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update2_kernel<R, L, HEAD, W>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1537,13 +1507,9 @@ template int upd2_inst<MLP_UPD_RELU, MLP_UPD_LN, 3>(bool, dim3, dim3, size_t, hi
 #ifdef MLP_TU_UPD2D
 template <bool R, int L, bool WA, bool WC>
 static int upd2d_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const DualArgs &d) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update2_dual_kernel<R, L, WA, WC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update2_dual_kernel<R, L, WA, WC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)LDS_DYN_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("actor_critic_update: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  if (e_ != hipSuccess) { mappo_set_error("actor_critic_update: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update2_dual_kernel<R, L, WA, WC>), grid, block, lds_bytes, st, d);
   return MAPPO_OK;
 }
@@ -1558,13 +1524,9 @@ template int upd2d_inst<MLP_UPD_RELU, MLP_UPD_LN>(bool, bool, dim3, dim3, size_t
 #ifdef MLP_TU_UPD16
 template <bool R, int L, int HEAD, bool W>
 static int upd16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16_kernel<R, L, HEAD, W>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)UPD16_LDS_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("update16: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  if (e_ != hipSuccess) { mappo_set_error("update16: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update16_kernel<R, L, HEAD, W>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1578,13 +1540,9 @@ template int upd16_inst<MLP_UPD_RELU, MLP_UPD_LN>(int, bool, dim3, dim3, size_t,
 
 template <bool R, int L, bool WA, bool WC>
 static int upd16d_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Dual16Args &d) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16_dual_kernel<R, L, WA, WC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16_dual_kernel<R, L, WA, WC>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)UPD16_LDS_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("actor_critic_update: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  if (e_ != hipSuccess) { mappo_set_error("actor_critic_update: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update16_dual_kernel<R, L, WA, WC>), grid, block, lds_bytes, st, d);
   return MAPPO_OK;
 }
@@ -1597,13 +1555,9 @@ template int upd16d_inst<MLP_UPD_RELU, MLP_UPD_LN>(bool, bool, dim3, dim3, size_
 
 template <bool R, int L, int HEAD>
 static int upd16x_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Upd16Args &a) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16x_kernel<R, L, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)mlp_update16x_kernel<R, L, HEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)UPD16_LDS_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("update16x: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  if (e_ != hipSuccess) { mappo_set_error("update16x: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_MLP_BWD, (mlp_update16x_kernel<R, L, HEAD>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1668,12 +1622,8 @@ int launch_features16(const FwdArgs &a_in, hipStream_t st);      // defined in t
 #ifdef MLP_TU_STEP
 template <bool R, int L>
 static int features16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const FwdArgs &a) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)features16_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("mlp_features: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)features16_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+  if (e_ != hipSuccess) { mappo_set_error("mlp_features: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   hipLaunchKernelGGL((features16_kernel<R, L>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1703,12 +1653,8 @@ int launch_features16(const FwdArgs &a_in, hipStream_t st) {
 
 template <bool R, int L>
 static int features16_dual_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const FwdArgs &a, const FwdArgs &c, int nA) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)features16_dual_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)features16_dual_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+  if (e_ != hipSuccess) { mappo_set_error("mlp_features_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   hipLaunchKernelGGL((features16_dual_kernel<R, L>), grid, block, lds_bytes, st, a, c, nA);
   return MAPPO_OK;
 }
@@ -1775,12 +1721,8 @@ extern "C" int mappo_mlp_features_dual(const float *params_a, const mappo_net_de
 // ---- fused rollout step (rollout_step_kernel): translation unit mlp_step.hip --------------------------------------
 template <bool R, int L>
 static int step_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const StepArgs &a) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)rollout_step_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("rollout_step: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr_set = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)rollout_step_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+  if (e_ != hipSuccess) { mappo_set_error("rollout_step: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_ACT, (rollout_step_kernel<R, L>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1863,8 +1805,7 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
   if (nb > NUM_CU) nb = NUM_CU;
   dim3 grid((unsigned)nb), block(WAVE * nw);
   {
-    const char *e16 = getenv("MAPPO_UPD16");
-    if (a.desc.in_dim > MAXD && a.desc.in_dim <= 512 && a.x_M == 0 && !(e16 && e16[0] == '0')) {
+    if (a.desc.in_dim > MAXD && a.desc.in_dim <= 512 && a.x_M == 0) {
       // wide inputs: layer 1 from registers + double-buffered W1 chunks, the rest of the network on the same tile (mlp_wide16.h)
       Wide16Args w;
       size_t lb;
@@ -1887,13 +1828,9 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
   }
 #define FWD2(R, L, W)                                                                                          \
   do {                                                                                                         \
-    static bool attr_set = false;                                                                              \
-    if (!attr_set) {                                                                                           \
-      hipError_t e_ = hipFuncSetAttribute((const void *)mlp_forward_kernel<R, L, MODE, W>,                      \
+    static const hipError_t e_ = hipFuncSetAttribute((const void *)mlp_forward_kernel<R, L, MODE, W>,                      \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);       \
-      if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; } \
-      attr_set = true;                                                                                         \
-    }                                                                                                          \
+    if (e_ != hipSuccess) { mappo_set_error("%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; } \
     PROF_LAUNCH(prof_id, (mlp_forward_kernel<R, L, MODE, W>), grid, block, lds_bytes, st, a);                   \
   } while (0)
 #define FWD_W(R, L) do { if (xw == 2) FWD2(R, L, 2); else if (xw == 1) FWD2(R, L, 1); else FWD2(R, L, 0); } while (0)
@@ -1944,8 +1881,6 @@ extern "C" int mappo_actor_act(const float *params, const mappo_net_desc *desc, 
 // ---- one wave per 16-sample tile (mlp_upd16.h) ---------------------------------------------------------------------
 #define UPD16_WAVES (UPD16_THREADS / WAVE)
 static bool upd16_eligible(const mappo_net_desc &d, bool actor) {
-  const char *e = getenv("MAPPO_UPD16");               // diagnostic switch: MAPPO_UPD16=0 keeps the pair kernel (A/B timing, cross-checks)
-  if (e && e[0] == '0') return false;
   return d.in_dim <= MAXD && d.layer_N <= 1 && !d.recurrent && (actor ? d.out_dim <= 16 : d.out_dim == 1);
 }
 // MFMA instructions per 16-sample tile (+ a flat allowance for the VALU phases): the share of the chip a network gets
@@ -1958,8 +1893,6 @@ static int upd16_tile_cost(const mappo_net_desc &d, bool actor) {
 }
 // trunk backward (gradient arriving at the trunk output; recurrent networks): same kernels, no head
 static bool upd16_trunk_eligible(const mappo_net_desc &d) {
-  const char *e = getenv("MAPPO_UPD16");
-  if (e && e[0] == '0') return false;
   return d.in_dim <= 512 && d.layer_N <= 1;
 }
 static size_t upd16_trunk_lds_floats(const mappo_net_desc &d) {
@@ -1988,26 +1921,24 @@ static int prep16(Upd16Args &a, bool actor, const char *who) {
 }
 // ---- wide inputs through the 16-sample-tile kernels ----
 static bool upd16x_eligible(const mappo_net_desc &d, bool actor) {
-  const char *e = getenv("MAPPO_UPD16");
-  if (e && e[0] == '0') return false;
   return d.in_dim > MAXD && d.in_dim <= 512 && d.layer_N <= 1 && !d.recurrent && (actor ? d.out_dim <= 16 : d.out_dim == 1);
 }
 static int64_t wide_z1_offset(int64_t B) { return wide16_z1_offset(B); }     // workspace layout: mlp_wide16.h (>= the [64][B] | mean0 | rstd0 of the round-1 kernels)
 
-// Which layout the last producer left in a wide workspace (dz1 blocked per tile + padded statistics: the 16x16x4 path; or the
-// round-1 kernels' feature-major [64][B] | mean0 [B] | rstd0 [B]) — mappo_wide_l1_backward picks the matching consumer.  Host
-// side, keyed by the workspace pointer: producer and consumer are enqueued by the same thread in stream order (and a graph
-// capture records the kernels chosen here).
-static std::mutex g_wide_layout_mu;
-static std::unordered_map<const void *, int> g_wide_layout;
-static void wide_layout_set(const void *ws, int blocked) {
-  std::lock_guard<std::mutex> lk(g_wide_layout_mu);
-  g_wide_layout[ws] = blocked;
+// The layout a producer leaves in a wide workspace is a pure function of (network descriptor, producer): mappo_wide_layout.
+// The caller passes it on to mappo_wide_l1_backward — no host-side state, nothing keyed by pointers.
+static int wide_layout_of(const mappo_net_desc &d, int producer) {
+  if (producer == MAPPO_PRODUCER_TRUNK_BACKWARD) return upd16_trunk_eligible(d) ? MAPPO_WIDE_LAYOUT_BLOCKED : MAPPO_WIDE_LAYOUT_FEATURE_MAJOR;
+  if (producer == MAPPO_PRODUCER_ACTOR_UPDATE || producer == MAPPO_PRODUCER_CRITIC_UPDATE)
+    return upd16x_eligible(d, producer == MAPPO_PRODUCER_ACTOR_UPDATE) ? MAPPO_WIDE_LAYOUT_BLOCKED : MAPPO_WIDE_LAYOUT_FEATURE_MAJOR;
+  return MAPPO_WIDE_LAYOUT_FEATURE_MAJOR;                        // mappo_mlp_backward (external gradient): K-chunked kernel
 }
-static int wide_layout_get(const void *ws) {
-  std::lock_guard<std::mutex> lk(g_wide_layout_mu);
-  auto it = g_wide_layout.find(ws);
-  return it == g_wide_layout.end() ? 0 : it->second;
+extern "C" int32_t mappo_wide_layout(const mappo_net_desc *desc, int32_t producer) {
+  if (!desc || producer < MAPPO_PRODUCER_MLP_BACKWARD || producer > MAPPO_PRODUCER_TRUNK_BACKWARD) {
+    mappo_set_error("wide_layout: bad arguments");
+    return MAPPO_EINVAL;
+  }
+  return wide_layout_of(*desc, producer);
 }
 static size_t upd16x_lds_floats(const mappo_net_desc &d, bool actor) {
   if (actor) return d.layer_N > 0 ? L16<1, 1, true, true>::TOTAL : L16<0, 1, true, true>::TOTAL;
@@ -2094,7 +2025,6 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
     if (int rcw = launch_wide_l1_fwd(a.params, d, a.off, a.x, a.rows, a.B, a.wide_ws + wide_z1_offset(a.B), a.wide_ws + 64 * wide16_bp(a.B),
                                      a.wide_ws + 65 * wide16_bp(a.B), st, who))
       return rcw;
-    wide_layout_set(a.wide_ws, 1);
     Upd16Args a16 = {};
     a16.u = a;
     if (HEAD == 3) {
@@ -2128,7 +2058,6 @@ static int launch_update(UpdArgs &a, hipStream_t st, const char *who) {
     MAPPO_REQUIRE(lds_bytes <= LDS_DYN_MAX, "%s: needs %zu B of LDS", who, lds_bytes);
     a.red_base = a.off.b1;
     MAPPO_REQUIRE(a.wide_ws, "%s: in_dim %d needs the wide workspace (mappo_wide_workspace_floats)", who, d.in_dim);
-    wide_layout_set(a.wide_ws, 0);                              // feature-major dz1 [64][B] | mean0 | rstd0
     const int p_span = a.p_red - a.red_base;
     a.n_regions = (nw > 1 && nw * a.map.wave_stride >= 2 * p_span) ? 2 : 1;
     MAPPO_REQUIRE(nw * a.map.wave_stride >= a.n_regions * p_span, "%s: reduction buffer too small", who);
@@ -2457,12 +2386,15 @@ extern "C" int32_t mappo_wide_l1_slabs(int64_t B) {
 
 extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
                                       int64_t B, const float *wide_ws, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                                      mappo_stream_t stream) {
+                                      int32_t layout, mappo_stream_t stream) {
   if (int rc = check_desc_trunk(desc, "wide_l1_backward")) return rc;
   MAPPO_REQUIRE(desc->in_dim > MAXD, "wide_l1_backward: in_dim %d is handled inside the update kernels", desc->in_dim);
   MAPPO_REQUIRE(params && x && wide_ws && slabs && B > 0, "wide_l1_backward: bad arguments");
+  MAPPO_REQUIRE(layout == MAPPO_WIDE_LAYOUT_BLOCKED || layout == MAPPO_WIDE_LAYOUT_FEATURE_MAJOR,
+                "wide_l1_backward: layout %d (pass mappo_wide_layout(desc, producer) of the launch that filled the workspace)", (int)layout);
+  MAPPO_REQUIRE(layout != MAPPO_WIDE_LAYOUT_BLOCKED || desc->in_dim <= 512, "wide_l1_backward: the blocked layout exists for in_dim <= 512 only");
   {
-    if (wide_layout_get(wide_ws) == 1) {
+    if (layout == MAPPO_WIDE_LAYOUT_BLOCKED) {
       // 16x16x4 kernel (mlp_wide16.h): raw products, every input element read once
       const NetOff o = net_offsets(*desc);
       MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + o.total <= slab_stride, "wide_l1_backward: slab column range");
@@ -2486,12 +2418,8 @@ extern "C" int mappo_wide_l1_backward(const float *params, const mappo_net_desc 
   a.off = net_offsets(*desc); a.B = B; a.D = desc->in_dim; a.use_feature_norm = desc->use_feature_norm;
   MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "wide_l1_backward: slab column range");
   const size_t lds_bytes = (size_t)(MAXD * WP + 2 * MAXD + 4 * 2 * HID * TP) * sizeof(float);
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
-    if (e_ != hipSuccess) { mappo_set_error("wide_l1_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    attr = true;
-  }
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+  if (e_ != hipSuccess) { mappo_set_error("wide_l1_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   dim3 grid((unsigned)mappo_wide_l1_slabs(B), (unsigned)((desc->in_dim + MAXD - 1) / MAXD));
   hipLaunchKernelGGL(wide_l1_bwd_kernel, grid, dim3(256), lds_bytes, as_stream(stream), a);
   MAPPO_CHECK_LAUNCH("wide_l1_backward");

@@ -923,19 +923,21 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
     __syncthreads();
   });
   STAMP(18);  // accumulator chunks
-  // the waves' loss sums into thread 0's registers HERE: two barriers follow before affine_epilogue16 reuses scr[0, 1024) as
-  // scratch (read any later, the eighth wave's scratch writes raced with this read: the value-loss statistic of a workgroup
-  // came out short now and then — the gradients never go through this slot)
   float lsum[M::N_WAVES * 4];
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int e = 0; e < M::N_WAVES * 4; ++e) lsum[e] = scr[960 + e];
-  }
   // per-feature vectors: {gB1, gB2, gBh, gWc} of every wave, wave w < 4 sums component w
   {
     f32x4 sv; sv[0] = gB1f; sv[1] = gB2f; sv[2] = gBhf; sv[3] = gWc;
     st4(cb + (wave * 64 + lane) * 4, sv);
     __syncthreads();
+    // the waves' loss sums into thread 0's registers HERE: behind a barrier that every instantiation executes after the
+    // scr[960..] writes (the accumulator-chunk loop above has ZERO trips when the kernel owns no MFMA accumulators — wide
+    // critic, layer_N = 0 — so its barriers cannot be relied on), and in front of the barrier below, after which
+    // affine_epilogue16 reuses scr[0, 1024) as scratch (read any later, the eighth wave's scratch writes raced with this
+    // read: the value-loss statistic of a workgroup came out short now and then — the gradients never go through this slot)
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int e = 0; e < M::N_WAVES * 4; ++e) lsum[e] = scr[960 + e];
+    }
     if (wave < 4) {
       float v = 0.f;
 #pragma unroll

@@ -232,7 +232,13 @@ extern "C" int mappo_ppo_loss_fwd_bwd(const float *logits, const float *values, 
   p.adv = adv; p.active = active; p.v_old = v_old; p.returns = returns; p.vn_state = vn_state; p.mb_moments = mb_moments;
   p.dlogits = dlogits; p.dvalues = dvalues; p.partials = (double *)workspace; p.cfg = *cfg; p.B = B; p.A = A;
   const int nblk = pl_blocks(B);
-  const size_t lds = (size_t)2 * PL_BLOCK * A * sizeof(float);      // logits / d(logits) tile + availability tile
+  // logits / d(logits) tile, + the availability tile only when the kernel stages it (avail given, rows streamed in place):
+  // same predicate as `av_lds` in the kernel — without it the second tile only halved the occupancy
+  const bool av_lds = avail != nullptr && rows == nullptr;
+  const size_t lds = (size_t)(av_lds ? 2 : 1) * PL_BLOCK * A * sizeof(float);      // <= 64 KiB at A = MAPPO_MAX_ACTIONS
+  static const hipError_t attr_rc = hipFuncSetAttribute((const void *)ppo_loss_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        (int)(2 * PL_BLOCK * MAPPO_MAX_ACTIONS * sizeof(float)));
+  if (attr_rc != hipSuccess) { mappo_set_error("ppo_loss: hipFuncSetAttribute: %s", hipGetErrorString(attr_rc)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
   PROF_LAUNCH(MAPPO_PROF_PPO_LOSS, ppo_loss_kernel, dim3(nblk), dim3(PL_BLOCK), lds, as_stream(stream), p);
   hipLaunchKernelGGL(ppo_stats_kernel, dim3(1), dim3(PL_BLOCK), 0, as_stream(stream), (const double *)workspace, nblk,
                      mb_moments, B, cfg->use_policy_active_masks, cfg->use_value_active_masks, stats);

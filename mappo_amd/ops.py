@@ -233,11 +233,23 @@ def mlp_backward_slabs(B):
     return int(_lib.load().mappo_mlp_backward_slabs(int(B)))
 
 
-def _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, wide_ws):
+PRODUCER_MLP_BACKWARD, PRODUCER_ACTOR_UPDATE, PRODUCER_CRITIC_UPDATE, PRODUCER_TRUNK_BACKWARD = 0, 1, 2, 3
+
+
+def wide_layout(desc, producer):
+    """Layout id the `producer` entry point leaves in a wide workspace for `desc` (a pure function: mappo_wide_layout)."""
+    v = int(_lib.load().mappo_wide_layout(C.byref(desc), int(producer)))
+    if v < 0:
+        _lib.check(v, "mappo_wide_layout")
+    return v
+
+
+def _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, wide_ws, producer):
     """Second launch of a wide-input (in_dim > 64) backward: W1 + feature-norm gradient columns."""
-    if desc.in_dim > 64:
+    if wide_ws is not None:
         rc = _lib.load().mappo_wide_l1_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(B),
-                                                _ptr(wide_ws), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+                                                _ptr(wide_ws), _ptr(slabs), int(slab_stride), int(slab_col0),
+                                                wide_layout(desc, producer), _stream())
         _lib.check(rc, "mappo_wide_l1_backward")
 
 
@@ -267,7 +279,7 @@ def mlp_backward(params, desc, x, rows, B, dout, slabs, slab_stride, slab_col0):
                                         int(B), _ptr(dout), _ptr(slabs), int(slab_stride), int(slab_col0),
                                         _ptr(ws, allow_none=True), _stream())
     _lib.check(rc, "mappo_mlp_backward")
-    _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, ws)
+    _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, ws, PRODUCER_MLP_BACKWARD)
 
 
 # ---- fused update kernels ------------------------------------------------------------------------
@@ -284,7 +296,7 @@ def actor_update(params, desc, obs, rows, B, avail, actions, old_logp, adv, acti
                                         int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), int(n_blocks),
                                         _stream())
     _lib.check(rc, "mappo_actor_update")
-    _wide(desc, obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
+    _wide(desc, obs, rows, B, slabs, slab_stride, slab_col0, params, ws, PRODUCER_ACTOR_UPDATE)
 
 
 def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_state, mb_moments, cfg, slabs, slab_stride,
@@ -296,7 +308,7 @@ def critic_update(params, desc, share_obs, rows, B, v_old, returns, active, vn_s
                                          int(slab_col0), _ptr(partials, torch.float64), _ptr(ws, allow_none=True), int(n_blocks),
                                          _stream())
     _lib.check(rc, "mappo_critic_update")
-    _wide(desc, share_obs, rows, B, slabs, slab_stride, slab_col0, params, ws)
+    _wide(desc, share_obs, rows, B, slabs, slab_stride, slab_col0, params, ws, PRODUCER_CRITIC_UPDATE)
 
 
 def dual_update_slabs(actor_desc, critic_desc, B):
@@ -420,7 +432,7 @@ def trunk_backward(params, desc, x, rows, B, dxT, slabs, slab_stride, slab_col0)
     rc = _lib.load().mappo_trunk_backward(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(B),
                                           _ptr(dxT), _ptr(slabs), int(slab_stride), int(slab_col0), _ptr(ws, allow_none=True), _stream())
     _lib.check(rc, "mappo_trunk_backward")
-    _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, ws)
+    _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, ws, PRODUCER_TRUNK_BACKWARD)
 
 
 # ---- K10 / K11 ------------------------------------------------------------------------------------

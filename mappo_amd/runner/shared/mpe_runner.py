@@ -97,8 +97,6 @@ class MPERunner(Runner):
                 self._next_values = torch.empty(b.n_rollout_threads * b.num_agents, device=b.device)
             nv = self.trainer.policy.collect_step_fused(b, self.episode_length, pending, self.use_centralized_V,
                                                         values_only=self._next_values)
-            if self._staging is not None:
-                self._staging.consumed()
             if nv is None:
                 self.insert(pending + (None,) * 6)
                 self.compute()
@@ -106,6 +104,8 @@ class MPERunner(Runner):
                 b.step = 0
                 self.trainer.prep_rollout()
                 b.compute_returns(nv, self.trainer.value_normalizer)
+            if self._staging is not None:
+                self._staging.consumed()                      # AFTER the fallback insert / compute: they read `pending`, too
             return infos
         self.compute()
         return infos

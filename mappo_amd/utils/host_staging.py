@@ -30,6 +30,7 @@ class HostStaging:
         self._k = 0            # upload slot of the current step
         self._up_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
         self._read_done = [None] * self.SLOTS      # compute-stream event: kernels that read slot k have been enqueued before it
+        self._pending_reads = []                   # per-upload events consumed() has not recorded yet
         self._dk = 0
         self._down_done = [torch.cuda.Event() for _ in range(self.SLOTS)]
 
@@ -91,6 +92,9 @@ class HostStaging:
                 out[n] = e["views"][k][n]
             cur = torch.cuda.current_stream(self.device)
             if self._read_done[k] is not None:
+                if self._read_done[k] in self._pending_reads:      # never consumed(): everything enqueued so far may read it
+                    self._read_done[k].record(cur)
+                    self._pending_reads.remove(self._read_done[k])
                 self.copy_stream.wait_event(self._read_done[k])    # kernels that still read the device twin of this slot
             with torch.cuda.stream(self.copy_stream):
                 e["dev"][k].copy_(e["host"][k], non_blocking=True)
@@ -98,16 +102,16 @@ class HostStaging:
             cur.wait_event(self._up_done[k])
             ev = torch.cuda.Event()
             self._read_done[k] = ev                          # recorded by consumed()
-            self._pending_read = ev
+            self._pending_reads.append(ev)                   # (two uploads without a consumed() in between: both stay protected)
         return out
 
     def consumed(self):
         """Call after enqueueing the kernels that read the tensors of the last upload(): their slot may be refilled once
         everything enqueued so far has run."""
-        ev = getattr(self, "_pending_read", None)
-        if ev is not None:
-            ev.record(torch.cuda.current_stream(self.device))
-            self._pending_read = None
+        cur = torch.cuda.current_stream(self.device)
+        for ev in self._pending_reads:
+            ev.record(cur)
+        self._pending_reads = []
 
     def download(self, name, tensor):
         """Device tensor -> NumPy array in pinned memory (valid until the call after next), waiting for this copy only."""

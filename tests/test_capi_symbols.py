@@ -41,3 +41,36 @@ def test_bad_arguments_return_error_codes_not_crashes():
     d = _lib.NetDesc(18, 128, 5, 1, 1, 1, 0)            # hidden 128 is not built
     rc = lib.mappo_mlp_forward(None, ctypes.byref(d), None, None, 4, None, None)
     assert rc == -1 and b"hidden_size" in lib.mappo_last_error()
+
+
+def test_wide_entry_points_reject_bad_arguments_and_layout_is_a_pure_function():
+    """mappo_wide_layout / mappo_wide_l1_backward (include/mappo_hip.h): argument validation happens before any launch, so the
+    error paths run without a GPU.  The layout a producer leaves is a function of (descriptor, producer) only — no host state."""
+    from mappo_amd import _lib, ops
+    lib = _lib.load()
+    wide_mlp = _lib.NetDesc(512, 64, 5, 1, 1, 1, 0)
+    wide_critic = _lib.NetDesc(512, 64, 1, 1, 1, 1, 0)
+    wide_l2 = _lib.NetDesc(176, 64, 18, 2, 1, 1, 0)       # layer_N = 2: K-chunked kernels
+    wide_rec = _lib.NetDesc(322, 64, 1, 1, 1, 1, 1)
+    narrow = _lib.NetDesc(54, 64, 1, 1, 1, 1, 0)
+    assert ops.wide_layout(wide_mlp, ops.PRODUCER_ACTOR_UPDATE) == 1 and ops.wide_layout(wide_mlp, ops.PRODUCER_MLP_BACKWARD) == 0
+    assert ops.wide_layout(wide_l2, ops.PRODUCER_ACTOR_UPDATE) == 0 and ops.wide_layout(wide_l2, ops.PRODUCER_TRUNK_BACKWARD) == 0
+    assert ops.wide_layout(wide_rec, ops.PRODUCER_TRUNK_BACKWARD) == 1 and ops.wide_layout(wide_rec, ops.PRODUCER_CRITIC_UPDATE) == 0
+    for _ in range(3):                                    # same answer every time, whatever was asked in between
+        assert ops.wide_layout(wide_critic, ops.PRODUCER_CRITIC_UPDATE) == ops.wide_layout(wide_mlp, ops.PRODUCER_ACTOR_UPDATE) == 1
+        assert ops.wide_layout(wide_mlp, ops.PRODUCER_CRITIC_UPDATE) == 0          # out_dim 5 is not a critic: K-chunked kernels
+    assert lib.mappo_wide_layout(None, 1) == -1 and lib.mappo_wide_layout(ctypes.byref(wide_mlp), 7) == -1
+    assert b"wide_layout" in lib.mappo_last_error()
+    fake = ctypes.c_void_p(4096)                          # non-NULL, never dereferenced: validation fails first
+    bw = lambda d, B, layout, ws=fake, stride=1 << 20: lib.mappo_wide_l1_backward(fake, ctypes.byref(d), fake, None, B, ws, fake, stride, 0,
+                                                                                  layout, None)
+    assert bw(narrow, 64, 1) == -1 and b"in_dim 54" in lib.mappo_last_error()
+    assert bw(wide_mlp, 0, 1) == -1 and b"bad arguments" in lib.mappo_last_error()
+    assert bw(wide_mlp, 64, 1, ws=None) == -1 and b"bad arguments" in lib.mappo_last_error()
+    assert bw(wide_mlp, 64, 2) == -1 and b"layout 2" in lib.mappo_last_error()
+    assert bw(wide_mlp, 64, -1) == -1 and b"layout -1" in lib.mappo_last_error()
+    assert bw(wide_mlp, 64, 1, stride=100) == -1 and b"slab column range" in lib.mappo_last_error()
+    assert lib.mappo_wide_workspace_floats(1000) >= 66 * 1000 and lib.mappo_wide_l1_slabs(76800) == 256
+    # producers without their workspace
+    rc = lib.mappo_trunk_backward(fake, ctypes.byref(wide_rec), fake, None, 64, fake, fake, 1 << 20, 0, None, None)
+    assert rc == -1 and b"wide workspace" in lib.mappo_last_error()

@@ -4,11 +4,13 @@ HIP kernels) against the reference's own outputs (tests/golden/*.npz) and the or
 Tolerances as in tests/test_oracle_golden.py: 1e-5 relative on losses / returns / forward outputs; post-Adam
 parameters carry an absolute floor of 3e-6 (lr = 7e-4: where |g| ~ eps the first Adam steps amplify an fp32
 re-association of g to ~0.3 % of lr — the oracle shows the same spread against the reference)."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
-from conftest import golden, sub
+from conftest import golden, sub, ROOT
 from oracle import mappo_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -190,7 +192,10 @@ def test_ppo_update_golden_variants(M, unfused):
         sample = tuple(d[f"sample/{nm}"] for nm in TUPLE)
         for rep in range(2 if fl["two_steps"] else 1):
             out = tr.ppo_update(sample, fl["update_actor"])
-            close(np.array(out, dtype=np.float64), d[f"r{rep}/stats"], 2e-5, 1e-7, f"case {c} stats")
+            # north_star: 1e-5 relative on losses.  policy_loss is a mean of O(1) terms of both signs (normalised advantages) that
+            # cancels to ~1e-2: the absolute floor is a few ulp of the TERMS, in the reference's own fp32 sum as much as in ours
+            _record_stat_errors("ppo_update" + ("_unfused" if unfused else ""), out, d[f"r{rep}/stats"])
+            close(np.array(out, dtype=np.float64), d[f"r{rep}/stats"], 1e-5, 2e-7, f"case {c} stats")
             for tag, net, opt, seg in (("actor", pol.actor, pol.actor_optimizer, 0), ("critic", pol.critic, pol.critic_optimizer, 1)):
                 ref_sd = sub(g, f"c{c}/r{rep}/{tag}")
                 for k, v in net.state_dict().items():
@@ -208,6 +213,29 @@ def test_ppo_update_golden_variants(M, unfused):
                 close(tr.value_normalizer.state, d[f"r{rep}/vn"], 2e-6, 1e-9)
         done += 1
     assert done >= 2
+
+
+STAT_NAMES = ("value_loss", "critic_grad_norm", "policy_loss", "dist_entropy", "actor_grad_norm", "ratio")
+_STAT_ERR = {}
+
+
+def _record_stat_errors(tag, got, ref):
+    """Max relative error per statistic over the fixture's cases; dumped to gpurun_out/stat_errors.json (committed under
+    profiles/ as the measured budget behind the tolerances of these tests)."""
+    import json
+    got, ref = np.asarray(got, dtype=np.float64).reshape(-1), np.asarray(ref, dtype=np.float64).reshape(-1)
+    e = _STAT_ERR.setdefault(tag, {})
+    for n, gv, rv in zip(STAT_NAMES, got, ref):
+        rel, ab = abs(gv - rv) / max(abs(rv), 1e-30), abs(gv - rv)
+        cur = e.get(n, dict(max_rel=0.0, max_abs=0.0, ref_at_max_rel=0.0))
+        if rel > cur["max_rel"]:
+            cur["max_rel"], cur["ref_at_max_rel"] = rel, rv
+        cur["max_abs"] = max(cur["max_abs"], ab)
+        e[n] = cur
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "stat_errors.json"), "w") as f:
+            json.dump(_STAT_ERR, f, indent=1, sort_keys=True)
 
 
 def test_ppo_update_small_hidden_rejected(M):
@@ -233,8 +261,11 @@ def test_train_golden_end_to_end(M, case, unfused):
     torch.manual_seed(3000 + case)
     info = tr.train(buf)
     ref = dict(zip([str(k) for k in d["info_keys"]], d["info"]))
+    _record_stat_errors(f"train_c{case}" + ("_unfused" if unfused else ""), [info[k] for k in STAT_NAMES], [ref[k] for k in STAT_NAMES])
     for k, v in info.items():
-        close(v, ref[k], 1e-4, 1e-7, k)
+        # averages over ppo_epoch x num_mini_batch updates whose parameters already differ by the Adam steps' rounding (each
+        # step moves a weight by ~lr = 7e-4 with a relative error of ~1e-4 of the step): 3e-5 relative measured at most
+        close(v, ref[k], 5e-5, 2e-7, k)
     for tag, net in (("actor1", pol.actor), ("critic1", pol.critic)):
         ref_sd = sub(g, f"c{case}/{tag}")
         for k, v in net.state_dict().items():

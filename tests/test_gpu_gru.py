@@ -540,3 +540,107 @@ def test_config3_full_size_train_vs_oracle_on_active_subset(M):
     for net, onet in ((pol.actor, opol.actor), (pol.critic, opol.critic)):
         for k, v in net.state_dict().items():
             close(v, onet.state_dict()[k].numpy(), 2e-4, 1e-5, k)
+
+
+def _random_fill(buf, A, g, active=None):
+    """Device-side random contents for a full-size buffer (the fill is not what is tested)."""
+    rnd = lambda shape: torch.randn(tuple(shape), device="cuda", generator=g)
+    for n in ("share_obs", "obs", "rnn_states", "rnn_states_critic", "rewards"):
+        getattr(buf, n).copy_(rnd(getattr(buf, n).shape))
+    buf.value_preds.copy_(rnd(buf.value_preds.shape) * 0.3)
+    buf.returns.copy_(rnd(buf.returns.shape) * 2)
+    buf.actions.copy_(torch.randint(0, A, tuple(buf.actions.shape), device="cuda", generator=g).float())
+    buf.action_log_probs.copy_(-rnd(buf.actions.shape).abs() - 1)
+    buf.masks.copy_((torch.rand(tuple(buf.masks.shape), device="cuda", generator=g) > 0.05).float())
+    buf.available_actions.fill_(1.0)                            # (all actions available: the stored actions were drawn uniformly)
+    if active is None:
+        active = (torch.rand(tuple(buf.active_masks.shape), device="cuda", generator=g) > 0.2).float()
+    buf.active_masks.copy_(active)
+
+
+def test_config5_shape_train_vs_oracle_multi_tile(M):
+    """BASELINE configs[4] SHAPE (64 agents, obs = state = 512, MLP policy) at T=40, N=20: 51 200 rows = 3 200 sixteen-row tiles,
+    more than the 2 048 waves of a launch, so R_MAPPO.train runs the wide-input update path in its steady state — the in-place
+    register refill of wide_l1_fwd16_kernel, the multi-tile loops of mlp_update16x_kernel and wide_l1_bwd16_kernel — and is
+    compared with the oracle's train on the SAME buffer (mlp.py:18-55, r_mappo.py:91-219): losses, gradient norms, weights."""
+    T, N, Ma, D, S, A = 40, 20, 64, 512, 512, 5
+    common = dict(episode_length=T, n_rollout_threads=N, lr=5e-4, critic_lr=5e-4, ppo_epoch=2, num_mini_batch=1)
+    a = make_args(M, perm_device="cpu", **common)
+    torch.manual_seed(21)
+    pol = M.R_MAPPOPolicy(a, [D], [S], M.Discrete(A))
+    tr = M.R_MAPPO(a, pol)
+    buf = M.SharedReplayBuffer(a, Ma, [D], [S], M.Discrete(A))
+    _random_fill(buf, A, torch.Generator(device="cuda").manual_seed(23))
+    oa = O.default_args(**common)
+    opol = O.PolicyRef(oa, D, S, A)
+    opol.actor.load_state_dict({k: v.cpu() for k, v in pol.actor.state_dict().items()})
+    opol.critic.load_state_dict({k: v.cpu() for k, v in pol.critic.state_dict().items()})
+    ob = O.BufferRef(oa, Ma, D, S, A)
+    for n in BUF_NAMES:
+        getattr(ob, n)[...] = getattr(buf, n).cpu().numpy()
+    ovn = O.ValueNormRef()
+    perms = [np.arange(T * N * Ma) for _ in range(2)]           # num_mini_batch == 1: the permutation only reorders sums
+    oinfo = O.train_ref(oa, opol, ovn, ob, perms=perms)
+    info = tr.train(buf)
+    for k in oinfo:
+        close(info[k], oinfo[k], 1e-4, 1e-6, k)
+    for net, onet in ((pol.actor, opol.actor), (pol.critic, opol.critic)):
+        for k, v in net.state_dict().items():
+            close(v, onet.state_dict()[k].numpy(), 1e-4, 6e-6, k)
+    close(tr.value_normalizer.state, ovn.state(), 1e-5, 1e-7, "ValueNorm state")
+
+
+def test_config4_per_gpu_size_train_vs_oracle_on_active_subset(M):
+    """BASELINE configs[3] at its PER-GPU size of an 8-GPU run (T=400, N=64 rollout threads, 10 agents, obs 176 / state 322 /
+    18 actions, GRU, chunks of 10, num_mini_batch=2: 256 000 rows, 12 800 chunks per minibatch): wide-input trunk features,
+    GRU training kernels and the wide trunk backward at the size where their tile loops iterate.  Same device as
+    test_config3_full_size_train_vs_oracle_on_active_subset: active_masks is zero except on four rollout threads, ValueNorm is
+    off, so train() on the full buffer must equal the oracle's train on the 4-thread sub-buffer.  With two minibatches the
+    chunk permutation matters: the full run's permutations put the kept threads' chunks into the SAME minibatch the oracle's
+    permutation of the sub-buffer puts them in (shared_buffer.py:385-494), padded with inactive chunks in random order."""
+    T, N, Ma, D, S, A, L, nmb, E = 400, 64, 10, 176, 322, 18, 10, 2, 2
+    keep = [3, 17, 40, 63]
+    common = dict(episode_length=T, lr=5e-4, critic_lr=5e-4, ppo_epoch=E, num_mini_batch=nmb, use_recurrent_policy=True,
+                  data_chunk_length=L, use_valuenorm=False)
+    a = make_args(M, n_rollout_threads=N, perm_device="cpu", algorithm_name="rmappo", **common)
+    torch.manual_seed(31)
+    pol = M.R_MAPPOPolicy(a, [D], [S], M.Discrete(A))
+    tr = M.R_MAPPO(a, pol)
+    buf = M.SharedReplayBuffer(a, Ma, [D], [S], M.Discrete(A))
+    g = torch.Generator(device="cuda").manual_seed(37)
+    act = torch.zeros(tuple(buf.active_masks.shape), device="cuda")
+    act[:, keep] = (torch.rand(act[:, keep].shape, device="cuda", generator=g) > 0.2).float()
+    _random_fill(buf, A, g, active=act)
+    oa = O.default_args(n_rollout_threads=len(keep), **common)
+    opol = O.PolicyRef(oa, D, S, A)
+    opol.actor.load_state_dict({k: v.cpu() for k, v in pol.actor.state_dict().items()})
+    opol.critic.load_state_dict({k: v.cpu() for k, v in pol.critic.state_dict().items()})
+    ob = O.BufferRef(oa, Ma, D, S, A)
+    for n in BUF_NAMES:
+        getattr(ob, n)[...] = getattr(buf, n)[:, keep].cpu().numpy()
+    # chunk c of a buffer with R series = series c // (T/L), time block c % (T/L); series = thread * Ma + agent
+    per = T // L
+    n_sub, n_full = len(keep) * Ma * per, N * Ma * per
+    rng = np.random.default_rng(41)
+    sub_perms, full_perms = [], []
+    for e in range(E):
+        sp = rng.permutation(n_sub)
+        k_idx, rest = sp // (Ma * per), sp % (Ma * per)
+        mapped = np.asarray(keep)[k_idx] * (Ma * per) + rest                     # the same chunks, indexed in the full buffer
+        inactive = rng.permutation(np.setdiff1d(np.arange(n_full), mapped))
+        hs, hf = n_sub // nmb, n_full // nmb
+        fp = []
+        for k in range(nmb):
+            part = np.concatenate([mapped[k * hs:(k + 1) * hs], inactive[k * (hf - hs):(k + 1) * (hf - hs)]])
+            fp.append(rng.permutation(part))                                     # order inside a minibatch only reorders sums
+        sub_perms.append(sp); full_perms.append(np.concatenate(fp))
+    oinfo = O.train_ref(oa, opol, None, ob, perms=sub_perms)
+    it = iter(full_perms)
+    buf._randperm = lambda n: torch.from_numpy(next(it)).to(buf.device)          # the permutation stream of recurrent_rows
+    info = tr.train(buf)
+    for k in oinfo:
+        if k != "ratio":
+            close(info[k], oinfo[k], 2e-4, 1e-6, k)
+    for net, onet in ((pol.actor, opol.actor), (pol.critic, opol.critic)):
+        for k, v in net.state_dict().items():
+            close(v, onet.state_dict()[k].numpy(), 2e-4, 1e-5, k)

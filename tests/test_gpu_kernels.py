@@ -435,14 +435,36 @@ def test_mlp_full_size_linearity(ops):
     close(out.cpu()[idx], ref, 1e-5, 2e-6)
 
 
+def _relu_margin(net, x):
+    """min |pre-activation| per row over the trunk's Linear layers (CPU oracle network).  ReLU'(z) jumps at z = 0: a row with a
+    pre-activation inside the fp32 rounding band of a D-term dot product may take the other branch on the GPU than in the
+    CPU reference, and ONE such element moves every gradient below it by one sample's worth (~ 1 / sqrt(B) of the entry, about
+    1e-3 of the largest at B = 70 000) — measured: scripts/dbg_wide_parity.py, a handful of flips per launch at B >= 16 384 and
+    D = 512, in either direction between any two implementations (fused, unfused, float64 autograd)."""
+    margins = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: margins.append(out.detach().abs().min(dim=1).values))
+             for m in net.base.mlp.modules() if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        net.base(x)
+    for h in hooks:
+        h.remove()
+    return torch.stack(margins).min(dim=0).values.numpy()
+
+
 @pytest.mark.parametrize("D,S,A,relu,B,with_rows", [(18, 54, 5, True, 3072, True), (18, 54, 5, False, 500, False),
                                                     (30, 48, 9, True, 333, True), (64, 64, 18, True, 100, False),
                                                     (18, 54, 5, True, 76800, False), (176, 322, 18, True, 700, True),
-                                                    (512, 512, 5, True, 260, False)])
+                                                    (512, 512, 5, True, 260, False),
+                                                    # wide inputs in their STEADY STATE: more 16-row tiles than the 2 048 waves of a
+                                                    # launch, so wide_l1_fwd16_kernel refills its row registers in place, and
+                                                    # mlp_update16x_kernel / wide_l1_bwd16_kernel walk several tiles per wave
+                                                    # (configs[3] / configs[4] sizes; ragged last tile; gathered rows in the second)
+                                                    (512, 512, 5, True, 70001, False), (176, 322, 18, True, 47019, True),
+                                                    (130, 65, 3, False, 33333, False)])
 def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, with_rows):
     """mappo_actor_update / mappo_critic_update (forward + in-kernel PPO loss + backward in one launch) against
     (a) the standalone sequence mlp_forward -> ppo_loss_fwd_bwd -> mlp_backward and (b) torch autograd through
-    the oracle networks with the reference's loss expressions."""
+    the oracle networks with the reference's loss expressions (mlp.py:18-55, r_mappo.py:91-164)."""
     torch.manual_seed(B + D)
     rng = np.random.default_rng(B + A)
     f = np.float32
@@ -462,6 +484,13 @@ def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, wit
     old_logp = (-np.abs(rng.standard_normal(n_rows)) * 0.3 - np.log(A)).astype(f)
     adv = rng.standard_normal(n_rows).astype(f)
     active = (rng.random(n_rows) > 0.25).astype(f)
+    if relu and B > 4000 and D > 64:
+        # large wide-input cases: rows whose ReLU pre-activations sit within 1e-4 of zero (about 1 % of them) are made inactive,
+        # so that all three implementations differentiate the SAME function (see _relu_margin); with the active-mask means
+        # (r_mappo.py:84,130-141) an inactive row contributes exactly nothing to any gradient
+        unsafe = np.minimum(_relu_margin(actor, torch.from_numpy(obs)), _relu_margin(critic, torch.from_numpy(sobs))) < 1e-4
+        assert 0 < unsafe.mean() < 0.05
+        active[unsafe] = 0.0
     ret = (rng.standard_normal(n_rows) * 3).astype(f)
     ret[rng.random(n_rows) > 0.9] *= 20
     with torch.no_grad():
@@ -515,9 +544,16 @@ def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, wit
     close(stats_f, stats_u, 1e-6, 1e-9, "stats fused vs unfused")
     close_rel_max(grad_f[:Pa], grad_u[:Pa].cpu().numpy(), 2e-5, "actor grad fused vs unfused")
     close_rel_max(grad_f[col_c:col_c + Pc], grad_u[col_c:col_c + Pc].cpu().numpy(), 2e-5, "critic grad fused vs unfused")
-    # (3) autograd through the oracle
-    if B <= 4000:
-        t = lambda x: torch.from_numpy(x)
+    # (3) autograd through the oracle (CPU torch; the narrow full-size case is covered by the e2e tests instead)
+    if B <= 4000 or D > 64:
+        if B > 4000:
+            # tens of thousands of terms per gradient entry: the CPU reference itself runs in float64, so that the tolerance
+            # below bounds the KERNELS' fp32 summation error and not the reference's
+            import copy
+            actor, critic = copy.deepcopy(actor).double(), copy.deepcopy(critic).double()
+            t = lambda x: torch.from_numpy(x).double()
+        else:
+            t = lambda x: torch.from_numpy(x)
         r_ = rows.astype(np.int64)
         lp, ent, _ = actor.evaluate_actions(t(obs[r_]), None, t(actions[r_]).view(-1, 1), None, t(avail[r_]), t(active[r_]).view(-1, 1))
         vals = critic(t(sobs[r_]), None, None)[0]
@@ -825,3 +861,56 @@ def test_dual_update_statistics_are_deterministic(ops):
     for _ in range(5):
         g, s = run(False)
         assert np.array_equal(g, gs) and np.array_equal(s, ss)
+
+
+def test_wide_critic_layer0_statistics_deterministic_and_vs_oracle(ops):
+    """mlp_update16x_kernel<R, 0, 2> — a wide-input critic (in_dim 65..512) with layer_N = 0 owns NO MFMA accumulators, so the
+    accumulator-chunk reduction of its epilogue has zero trips: the barrier that orders the waves' loss partial sums before thread
+    0 reads them must not depend on that loop (regression for a race that shortened a workgroup's value-loss partial now and
+    then).  A buffer on which all eight waves of every workgroup have tiles; 30 launches bit-identical, and the value loss equal
+    to the reference expression (r_mappo.py:52-89) evaluated by the oracle network on the CPU."""
+    B, D = 40000, 130
+    a = O.default_args(layer_N=0)
+    cfg = ops.ppo_cfg(a)
+    critic = O.CriticRef(a, D); _randomize(critic, 6)
+    dc = ops.net_desc(D, 1, 0, True, True)
+    pc, lc, Pc = _flat_from_module(ops, critic, dc, "v_out")
+    P = ((Pc + 255) // 256) * 256
+    rng = np.random.default_rng(5)
+    f = np.float32
+    sobs = rng.standard_normal((B, D)).astype(f)
+    ret = (rng.standard_normal(B) * 3).astype(f)
+    active = (rng.random(B) > 0.25).astype(f)
+    with torch.no_grad():
+        v_now = critic(torch.from_numpy(sobs), None, None)[0].numpy().reshape(-1)
+    v_old = (v_now + rng.standard_normal(B) * 0.25).astype(f)
+    vn = O.ValueNormRef(); vn.update(ret.reshape(-1, 1))
+    g = dict(sobs=dev(sobs), ret=dev(ret), active=dev(active), vold=dev(v_old), vn=dev(vn.state()))
+    mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ops.minibatch_moments(g["ret"], g["active"], None, B, mom)
+    ns = ops.mlp_backward_slabs(B)
+
+    def run():
+        slabs = torch.zeros(ns, P, device="cuda")
+        part = ops.update_partials("cuda")
+        ops.critic_update(pc, dc, g["sobs"], None, B, g["vold"], g["ret"], g["active"], g["vn"], mom, cfg, slabs, P, 0, part)
+        stats = torch.zeros(6, dtype=torch.float64, device="cuda")
+        ops.update_stats(None, ns, part, ns, mom, cfg, stats)
+        return slabs.double().sum(0).cpu().numpy(), stats.cpu().numpy()
+
+    g0, s0 = run()
+    for _ in range(30):
+        gi, si = run()
+        assert np.array_equal(gi, g0) and np.array_equal(si, s0)
+    t = torch.from_numpy
+    vals = critic(t(sobs), None, None)[0]
+    act_t = t(active).view(-1, 1)
+    tgt = vn.normalize(t(ret).view(-1, 1))
+    vo = t(v_old).view(-1, 1)
+    vclip = vo + (vals - vo).clamp(-a.clip_param, a.clip_param)
+    l = torch.max(O.huber_ref(tgt - vals, a.huber_delta), O.huber_ref(tgt - vclip, a.huber_delta))
+    vl = (l * act_t).sum() / act_t.sum()
+    (vl * a.value_loss_coef).backward()
+    close(s0[0], vl.item(), 1e-5, 1e-7, "value loss vs oracle")
+    for key, off, shape in lc:
+        close_rel_max(g0[off: off + int(np.prod(shape))].reshape(shape), dict(critic.named_parameters())[key].grad.numpy(), 1e-4, f"critic {key}")
