@@ -78,6 +78,15 @@ SIGNATURES = {
                                       _P, _P, _P, _P, _P]),
     "mappo_recurrent_step_dual": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, _P, C.POINTER(NetDesc), _P, _P, _P, _P, _I32, _P, _I32, _U64, _U64,
                                       _P, _P, _P, _P, _P]),
+    "mappo_gru16_scratch_floats": (_I64, [_I32, _I32]),
+    "mappo_gru16_blocked_floats": (_I64, [_I32, _I32]),
+    "mappo_gru16_slabs": (_I32, [_I32, _I32]),
+    "mappo_mlp_features_seq": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P]),
+    "mappo_gru16_forward_loss": (C.c_int, [_P, C.POINTER(NetDesc), _P, _I32, _P, _P, _P, _P, _I32, _I32, _I32] + [_P] * 9 +
+                                 [C.POINTER(PpoCfg), _P, _P, _I64, _I64, _P, _P]),
+    "mappo_gru16_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _P]),
+    "mappo_gru16_wgrad": (C.c_int, [C.POINTER(NetDesc), _P, _I32, _P, _I32, _I32, _P, _I64, _I64, _P]),
+    "mappo_trunk_backward_seq": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _I64, _I64, _P]),
     "mappo_mlp_features_dual": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, C.POINTER(NetDesc), _P, _P, _I64, _P]),
     "mappo_gru_backward_slabs": (_I32, [_I32]),
     "mappo_gru_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, _I32, _I32, _I32] + [_P] * 9 + [C.POINTER(PpoCfg), _P, _P, _P, _P,

@@ -1,0 +1,823 @@
+// gru_train16.hip — the TRAINING pass of the recurrent layer (onpolicy/algorithms/utils/rnn.py:25-79 inside
+// r_mappo.py:91-164's evaluate_actions + loss + backward) on v_mfma_f32_16x16x4_f32, one wavefront per 16-SEQUENCE tile.
+//
+// Round-2 state (gru.hip: gru_gi / gru_fwd_train2 / gru_head_bwd / gru_cell_bwd2 / gru_dx / gru_wgrad, 32x32x2 tiles, feature-major
+// scratch): six launches per network whose recurrences ran at 0.12-0.14 of the fp32 MFMA rate — every per-step value went
+// through HBM as 4-byte accesses 128 B apart, the input-side products had their own launches and scratch, and the two waves of a
+// tile met at a barrier every step.  Here:
+//
+//   gru16_fwd_kernel    per step t of a tile: gi = W_ih x_t AND gh = W_hh (h mask) in ONE accumulator set (the input products are
+//                       independent of the recurrence: they fill the dependent chain's bubbles), gates, h_t; then — still in
+//                       registers — rnn.norm, the head, the PPO / value loss and their backward, so that what leaves the wave is
+//                       d h_t (without the recurrent term) and the gate values the cell backward needs.  gi and h_t never
+//                       reach HBM; head / rnn.norm gradients and the loss sums are reduced per workgroup.
+//   gru16_bwd_kernel    reverse time: d gates from (d h_t + carry); carry = (W_hh^T d gh + d h z) mask AND d x_t = W_ih^T d gi
+//                       from the same registers (again independent work beside the dependent chain); d gates / d x overwrite the
+//                       forward's slots in place.
+//   gru16_wgrad_kernel  dW_ih, dW_hh, db_ih, db_hh = sum over rows of (d gates)^T (x | h mask): row-tile GEMMs, 4 roles per tile.
+//
+// Layouts.  16x16x4 accumulator layout: lane (n = lane & 15, q = lane >> 4) holds features 16 b + 4 q + i (b, i = 0..3) of
+// sequence n; the reduction order over k is free, so k-step (b, i) takes k = 16 b + 4 q + i and a lane's own registers are
+// the B operand (mlp_upd16.h).  Weights sit in LDS in FRAGMENT order: block (bo, b) of a row-major [G][K] matrix is 256 floats,
+// lane (n, q) owning M[16 bo + n][16 b + 4 q + 0..3] at float offset 4 * lane — the A operand of four MFMAs as ONE 16-byte read
+// at base + 16 * lane bytes: every 16-lane group of a ds_read_b128 covers all 64 banks exactly once (a row-major copy with
+// stride 68 puts lanes (11, q) and (12, q - 1) of a group on the same bank quad: one conflict cycle in five).  Scratch is
+// BLOCKED the same way: [component][t][tile][b][lane][4] — a wave instruction moves one contiguous KiB.
+#include <stdlib.h>
+#define MLP_TU_GRU16
+#include "mlp_impl.h"
+
+#define G16_THREADS 512
+#define G16_WAVES (G16_THREADS / WAVE)
+#define G16_NG 192
+#define G16_COMPS 6
+#define C_HM 0      // h_{t-1} * mask_t                           (backward: read by the weight-gradient kernel)
+#define C_R 1       // r          -> d pre_r  (backward, in place)
+#define C_Z 2       // z          -> d pre_z
+#define C_N 3       // n          -> d pre_n  (= d gi_n)
+#define C_GHN 4     // W_hn h + b_hn -> d gh_n (= d pre_n * r)
+#define C_DH 5      // d h_t without the recurrent term (forward) -> d x_t (backward, blocked x only)
+
+__device__ __forceinline__ float sigmoid16(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x)); }
+__device__ __forceinline__ float tanh16(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.88539008177792681f * x)); }
+
+struct Gru16Args {
+  const float *params;
+  NetOff off;
+  const float *x;             // trunk features: blocked [L][n_ct][4][256] (x_blocked) | feature-major [64][L * Nc]
+  int x_blocked;
+  const float *h0;            // [.][64] row-major initial states
+  const int32_t *h0_rows;     // [Nc] or NULL (identity)
+  const float *masks;         // buffer order, indexed by rows[t * Nc + c] (NULL rows: identity)
+  const int32_t *rows;
+  int L, Nc, A;
+  float *scratch;             // [6][L][n_ct][4][256]
+  const float *avail, *actions, *old_logp, *adv, *active, *v_old, *returns, *vn_state;
+  const double *mb_moments;
+  mappo_ppo_cfg cfg;
+  float *dxT;                 // backward: feature-major d x [64][L * Nc], or NULL: blocked, in scratch component C_DH
+  float *slabs;
+  int64_t slab_stride, slab_col0;
+  double *partials;           // [grid][4]
+};
+
+// ---- staging -----------------------------------------------------------------------------------------------------------------
+// dst block (bo, b) <- M[16 bo + n][16 b + 4 q + i], M row-major [G][K] (rows >= g_valid read as zero); one 16-byte global
+// load -> one 16-byte LDS store; all loads of a batch are issued before the first store
+template <int NB>
+__device__ __forceinline__ void stage_frag(float *dst, const float *__restrict__ src, int G, int K, int g_valid) {
+  const int k4 = K >> 2, n4 = G * k4, kb = K >> 4;
+  for (int e0 = threadIdx.x; e0 < n4; e0 += NB * G16_THREADS) {
+    float4 v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int e = min(e0 + j * G16_THREADS, n4 - 1), g = e / k4;
+      v[j] = reinterpret_cast<const float4 *>(src)[min(g, g_valid - 1) * k4 + (e - g * k4)];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int e = e0 + j * G16_THREADS;
+      if (e < n4) {
+        const int g = e / k4, kq = e - g * k4;
+        const float4 t = g < g_valid ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(dst + (((g >> 4) * kb + (kq >> 2)) * 64 + (kq & 3) * 16 + (g & 15)) * 4) = t;
+      }
+    }
+  }
+}
+// transposed copy: dst block (bo, b) <- M[16 b + 4 q + i][16 bo + n]  (out block over K, k-steps over G)
+template <int NB>
+__device__ __forceinline__ void stage_frag_T(float *dst, const float *__restrict__ src, int G, int K) {
+  const int k4 = K >> 2, n4 = G * k4, gb = G >> 4;
+  for (int e0 = threadIdx.x; e0 < n4; e0 += NB * G16_THREADS) {
+    float4 v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = reinterpret_cast<const float4 *>(src)[min(e0 + j * G16_THREADS, n4 - 1)];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int e = e0 + j * G16_THREADS;
+      if (e < n4) {
+        const int g = e / k4, kq = e - g * k4;
+        const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+        float *d = dst + (g >> 4) * 256 + ((g >> 2) & 3) * 64 + (g & 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = 4 * kq + r;
+          d[((k >> 4) * gb) * 256 + (k & 15) * 4] = vv[r];
+        }
+      }
+    }
+  }
+}
+
+// acc[bo] += M[16 (bo0 + bo) + n][16 b + 4 q + i] * v[b][i] over all 16 k-steps: FOUR output blocks at a time, so that four
+// independent accumulators sit between two MFMAs of one chain (dependent latency 40 cycles against 32 of issue)
+template <int KB>
+__device__ __forceinline__ void frag_mma4(f32x4 (&acc)[4], const float *W, int bo0, const f32x4 (&v)[4], int lane) {
+  const float *base = W + bo0 * KB * 256 + lane * 4;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    f32x4 a[4];
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(base + (bo * KB + b) * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) acc[bo] = mfma16(a[bo][i], v[b][i], acc[bo]);
+  }
+}
+
+// actor objective of one sample, NBH head blocks: lane (n, q) holds z[bo][i] = logit of action 16 bo + 4 q + i (A <= 16 NBH).
+// On return z = d(actor objective)/d logits.  Expressions of actor_loss_quad (mlp_upd16.h) / actor_loss_regs (mlp_core.h).
+template <int NBH>
+__device__ __forceinline__ void actor_loss_q16(f32x4 (&z)[NBH], int A, int q, uint32_t dead, int act, float old_lp, float adv, float active,
+                                               bool count, const mappo_ppo_cfg &cfg, float scale_pi, float (&lacc)[3]) {
+  const float clip = cfg.clip_param;
+  float zm = -FLT_MAX;
+  bool valid[NBH][4];
+#pragma unroll
+  for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      valid[bo][i] = 16 * bo + 4 * q + i < A;
+      if ((dead >> (4 * bo + i)) & 1u) z[bo][i] = -1e10f;
+      if (valid[bo][i]) zm = fmaxf(zm, z[bo][i]);
+    }
+  const float zmax = quad_max16(zm);
+  float e[NBH][4], se = 0.f;
+#pragma unroll
+  for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e[bo][i] = valid[bo][i] ? expf(z[bo][i] - zmax) : 0.f; se += e[bo][i]; }
+  se = quad_sum16(se);
+  const float log_se = logf(se), inv_se = 1.0f / se;
+  float hp = 0.f, za = 0.f;
+#pragma unroll
+  for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float l_ = (z[bo][i] - zmax) - log_se;
+      if (valid[bo][i]) hp += (e[bo][i] * inv_se) * fmaxf(l_, -FLT_MAX);
+      if (valid[bo][i] && 16 * bo + 4 * q + i == act) za = z[bo][i];
+    }
+  const float H = -quad_sum16(hp);
+  const float z_act = quad_sum16(za);                     // one lane / register of the sample is non-zero: exact
+  const float logp = (z_act - zmax) - log_se;
+  const float ratio = expf(logp - old_lp);
+  const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * adv;
+  const float w = cfg.use_policy_active_masks ? active : 1.f;
+  const float dlogp = (s1 <= s2) ? -(w * scale_pi) * adv * ratio : 0.f;
+  const float ce = cfg.entropy_coef * w * scale_pi;
+#pragma unroll
+  for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float l_ = (z[bo][i] - zmax) - log_se;
+      const float pa = e[bo][i] * inv_se;
+      float g = dlogp * ((16 * bo + 4 * q + i == act ? 1.f : 0.f) - pa) + ce * pa * (l_ + H);
+      if (!valid[bo][i] || ((dead >> (4 * bo + i)) & 1u) || !count) g = 0.f;
+      z[bo][i] = g;
+    }
+  if (count && q == 0) {
+    lacc[0] += w * fminf(s1, s2);
+    lacc[1] += w * H;
+    lacc[2] += ratio;
+  }
+}
+
+// ---- LDS maps ------------------------------------------------------------------------------------------------------------------
+template <int HEAD, int NBH>
+struct F16Lds {
+  static constexpr int DLS = NBH == 1 ? 20 : 36;                 // row stride of the d(logits) tile
+  static constexpr int WIH = 0, WHH = WIH + G16_NG * HID, BIAS = WHH + G16_NG * HID;     // b_r + b_r', b_z + b_z', b_in, b_hn
+  static constexpr int RN_G = BIAS + 4 * HID, RN_B = RN_G + HID;
+  static constexpr int WH = RN_B + HID;                          // actor: head weights, fragment order [NBH][4][256] | critic: [64]
+  static constexpr int BH = WH + (HEAD == 1 ? NBH * 4 * 256 : HID);
+  static constexpr int TILES = BH + 32;
+  static constexpr int UY = 0, UDL = UY + 16 * RS16, WAVE_STRIDE = UDL + (HEAD == 1 ? 16 * DLS : 0);
+  static constexpr int TOTAL = TILES + G16_WAVES * WAVE_STRIDE;
+  static_assert(TOTAL * 4 <= 159 * 1024, "gru16 forward: LDS");
+  static_assert(G16_WAVES * NBH * 4 * 256 <= 2 * G16_NG * HID, "epilogue overlays the GRU weights");
+};
+
+// ================================================================================================================================
+// forward + head + loss + head backward
+// ================================================================================================================================
+template <int HEAD, int NBH, bool XBLK>
+__device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, const int bid, const int nb) {
+  typedef F16Lds<HEAD, NBH> M;
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int A = p.A;
+  // ---- staging ----
+  stage_frag<6>(lds + M::WIH, p.params + o.gru_wih, G16_NG, HID, G16_NG);
+  stage_frag<6>(lds + M::WHH, p.params + o.gru_whh, G16_NG, HID, G16_NG);
+  {
+    const int tid = threadIdx.x;
+    if (tid < 4 * HID) {
+      const int gate = tid >> 6, f = tid & 63;
+      float v;
+      if (gate < 2) v = p.params[o.gru_bih + tid] + p.params[o.gru_bhh + tid];
+      else if (gate == 2) v = p.params[o.gru_bih + 2 * HID + f];
+      else v = p.params[o.gru_bhh + 2 * HID + f];
+      lds[M::BIAS + tid] = v;
+    } else if (tid < 5 * HID) lds[M::RN_G + (tid - 4 * HID)] = p.params[o.rn_w + (tid - 4 * HID)];
+    else if (tid < 6 * HID) lds[M::RN_B + (tid - 5 * HID)] = p.params[o.rn_b + (tid - 5 * HID)];
+    else if (tid < 6 * HID + 32) {
+      const int a = tid - 6 * HID;
+      lds[M::BH + a] = a < A ? p.params[o.bh + a] : 0.f;
+    }
+    if constexpr (HEAD == 1) stage_frag<2>(lds + M::WH, p.params + o.wh, 16 * NBH, HID, A);
+    else if (tid < HID) lds[M::WH + tid] = p.params[o.wh + tid];
+  }
+  __syncthreads();
+  float *Uy = lds + M::TILES + wave * M::WAVE_STRIDE + M::UY;
+  float *Udl = lds + M::TILES + wave * M::WAVE_STRIDE + M::UDL;
+  LossScales ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
+  ls.scale_pi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.scale_pi)));
+  ls.scale_v = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.scale_v)));
+  ls.vn_mean = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.vn_mean)));
+  ls.vn_sd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.vn_sd)));
+  float lacc[3] = {0.f, 0.f, 0.f};
+  f32x4 gWh[HEAD == 1 ? NBH : 1][HEAD == 1 ? 4 : 1];
+  float gBh[HEAD == 1 ? NBH : 1];
+  float gWc = 0.f, gNw = 0.f, gNb = 0.f;                          // critic head product / rnn.norm gradients: lane = feature
+#pragma unroll
+  for (int bo = 0; bo < (HEAD == 1 ? NBH : 1); ++bo) {
+    gBh[bo] = 0.f;
+#pragma unroll
+    for (int bk = 0; bk < (HEAD == 1 ? 4 : 1); ++bk) gWh[bo][bk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int n_ct = (p.Nc + 15) >> 4;
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t CS = (int64_t)p.L * n_ct * 1024;                  // floats per scratch component
+  for (int tile = bid * G16_WAVES + wave; tile < n_ct; tile += nb * G16_WAVES) {
+    const int c = tile * 16 + n;
+    const bool ok = c < p.Nc;
+    const int cc = ok ? c : 0;
+    const int64_t hrow = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
+    f32x4 h[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) h[b] = ld4(p.h0 + hrow * HID + 16 * b + 4 * q);
+    for (int t = 0; t < p.L; ++t) {
+      const int64_t col = (int64_t)t * p.Nc + cc;
+      const int64_t brow = p.rows ? (int64_t)p.rows[col] : col;
+      // ---- this step's inputs: everything is requested before the first use ----
+      f32x4 x[4];
+      if constexpr (XBLK) {
+        const float *xb = p.x + ((int64_t)(t * n_ct + tile) * 4) * 256 + lane * 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) x[b] = ld4(xb + b * 256);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[b][i] = p.x[(int64_t)(16 * b + 4 * q + i) * B + col];
+      }
+      float mk = p.masks[brow];
+      float f0, f1, f2, f3 = 0.f;
+      uint32_t dead = 0u;
+      if constexpr (HEAD == 1) {
+        f0 = p.actions[brow]; f1 = p.old_logp[brow]; f2 = p.adv[brow]; f3 = p.active[brow];
+        if (p.avail) {
+          const float *av = p.avail + brow * A;
+          float v[NBH][4];
+#pragma unroll
+          for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[bo][i] = av[min(16 * bo + 4 * q + i, A - 1)];
+#pragma unroll
+          for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dead |= ((16 * bo + 4 * q + i < A && v[bo][i] == 0.f) ? 1u : 0u) << (4 * bo + i);
+        }
+      } else {
+        f0 = p.v_old[brow]; f1 = p.returns[brow]; f2 = p.active[brow];
+      }
+      mk = ok ? mk : 0.f;
+      f32x4 hm[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) hm[b] = h[b] * f32x4{mk, mk, mk, mk};
+      // ---- gates: gi + gh, 384 MFMAs in four-accumulator groups ----
+      f32x4 ar[4], az[4], ain[4], ahn[4];
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) {
+        ar[bo] = ld4(lds + M::BIAS + 16 * bo + 4 * q);
+        az[bo] = ld4(lds + M::BIAS + HID + 16 * bo + 4 * q);
+        ain[bo] = ld4(lds + M::BIAS + 2 * HID + 16 * bo + 4 * q);
+        ahn[bo] = ld4(lds + M::BIAS + 3 * HID + 16 * bo + 4 * q);
+      }
+      frag_mma4<4>(ar, lds + M::WHH, 0, hm, lane);
+      frag_mma4<4>(az, lds + M::WHH, 4, hm, lane);
+      frag_mma4<4>(ahn, lds + M::WHH, 8, hm, lane);
+      frag_mma4<4>(ar, lds + M::WIH, 0, x, lane);
+      frag_mma4<4>(az, lds + M::WIH, 4, x, lane);
+      frag_mma4<4>(ain, lds + M::WIH, 8, x, lane);
+      float *sb = p.scratch + ((int64_t)(t * n_ct + tile) * 4) * 256 + lane * 4;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        f32x4 r, z, nn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          r[i] = sigmoid16(ar[b][i]);
+          z[i] = sigmoid16(az[b][i]);
+          nn[i] = tanh16(ain[b][i] + r[i] * ahn[b][i]);
+          h[b][i] = (1.f - z[i]) * nn[i] + z[i] * hm[b][i];
+        }
+        st4(sb + C_HM * CS + b * 256, hm[b]);
+        st4(sb + C_R * CS + b * 256, r);
+        st4(sb + C_Z * CS + b * 256, z);
+        st4(sb + C_N * CS + b * 256, nn);
+        st4(sb + C_GHN * CS + b * 256, ahn[b]);
+      }
+      // ---- y = rnn.norm(h_t) (rnn.py:79), head, loss, and back to d h_t ----
+      f32x4 xh[4], y[4];
+      float mean, rstd;
+      {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s += h[b];
+        mean = quad_sum16((s[0] + s[1]) + (s[2] + s[3])) * (1.f / HID);
+        const f32x4 mean4 = {mean, mean, mean, mean};
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { xh[b] = h[b] - mean4; v += xh[b] * xh[b]; }
+        rstd = 1.0f / sqrtf(quad_sum16((v[0] + v[1]) + (v[2] + v[3])) * (1.f / HID) + LN_EPS);
+        const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { xh[b] *= rstd4; y[b] = xh[b] * ld4(lds + M::RN_G + 16 * b + 4 * q) + ld4(lds + M::RN_B + 16 * b + 4 * q); }
+      }
+      f32x4 dy[4];
+      if constexpr (HEAD == 1) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, y[b]);
+        f32x4 zl[NBH];
+#pragma unroll
+        for (int bo = 0; bo < NBH; ++bo) zl[bo] = ld4(lds + M::BH + 16 * bo + 4 * q);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          f32x4 a[NBH];
+#pragma unroll
+          for (int bo = 0; bo < NBH; ++bo) a[bo] = ld4(lds + M::WH + ((bo * 4 + b) * 64 + lane) * 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int bo = 0; bo < NBH; ++bo) zl[bo] = mfma16(a[bo][i], y[b][i], zl[bo]);
+        }
+        actor_loss_q16<NBH>(zl, A, q, dead, (int)f0, f1, f2, f3, ok, p.cfg, ls.scale_pi, lacc);
+#pragma unroll
+        for (int bo = 0; bo < NBH; ++bo) st4(Udl + n * M::DLS + 16 * bo + 4 * q, zl[bo]);
+        wave_lds_sync();
+        dw_accum16<NBH, 4>(gWh, gBh, Udl, M::DLS, Uy, RS16, n, q);
+        // d y = Wh^T dl: out block bk, k-step (bo, i) takes action 16 bo + 4 q + i; A operand Wh[16 bo + 4 q + i][16 bk + n] sits in
+        // fragment (bo, bk) at lane' = (4 q + i, n >> 2), element n & 3
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk) dy[bk] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const float *wt = lds + M::WH + ((n >> 2) * 16 + 4 * q) * 4 + (n & 3);
+#pragma unroll
+        for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float a[4];
+#pragma unroll
+            for (int bk = 0; bk < 4; ++bk) a[bk] = wt[(bo * 4 + bk) * 256 + 4 * i];
+#pragma unroll
+            for (int bk = 0; bk < 4; ++bk) dy[bk] = mfma16(a[bk], zl[bo][i], dy[bk]);
+          }
+        wave_lds_sync();
+      } else {
+        f32x4 wv[4];
+        float acc = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          wv[b] = ld4(lds + M::WH + 16 * b + 4 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc += wv[b][i] * y[b][i];
+        }
+        const float v = quad_sum16(acc) + lds[M::BH];
+        float dv = critic_loss16(v, f0, f1, f2, p.cfg, ls, ok && q == 0, lacc);
+        dv = ok ? dv : 0.f;
+        if (q == 0) gBh[0] += dv;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          st4(Uy + n * RS16 + 16 * b + 4 * q, y[b] * f32x4{dv, dv, dv, dv});
+          dy[b] = wv[b] * f32x4{dv, dv, dv, dv};
+        }
+        wave_lds_sync();
+        gWc += col_sum16(Uy, RS16, lane);
+        wave_lds_sync();
+      }
+      // rnn.norm backward: d gamma = sum dy o xhat, d beta = sum dy (column sums through the wave's tile), then d h
+#pragma unroll
+      for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, dy[b] * xh[b]);
+      wave_lds_sync();
+      gNw += col_sum16(Uy, RS16, lane);
+      wave_lds_sync();
+#pragma unroll
+      for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, dy[b]);
+      wave_lds_sync();
+      gNb += col_sum16(Uy, RS16, lane);
+      wave_lds_sync();
+      {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { dy[b] *= ld4(lds + M::RN_G + 16 * b + 4 * q); s1 += dy[b]; s2 += dy[b] * xh[b]; }
+        const float m1 = quad_sum16((s1[0] + s1[1]) + (s1[2] + s1[3])) * (1.f / HID);
+        const float m2 = quad_sum16((s2[0] + s2[1]) + (s2[2] + s2[3])) * (1.f / HID);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          f32x4 d;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) d[i] = rstd * (dy[b][i] - m1 - xh[b][i] * m2);
+          st4(sb + C_DH * CS + b * 256, d);
+        }
+      }
+    }
+  }
+  // ---- workgroup reduction -> slab row `bid`, loss partials ----
+  __syncthreads();                                               // every wave is done with the weights: their area is free
+  float *red = lds;                                              // [wave][NBH * 4][256] head products | vectors behind them
+  float *vec = lds + G16_WAVES * NBH * 4 * 256;                  // [wave][8][64]: gNw, gNb, gWc | gBh[bo] (actor: lane n = action 16 bo + n), loss sums
+  if constexpr (HEAD == 1) {
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+      for (int bk = 0; bk < 4; ++bk) st4(red + ((wave * NBH * 4 + bo * 4 + bk) * 64 + lane) * 4, gWh[bo][bk]);
+  }
+  vec[(wave * 8 + 0) * 64 + lane] = gNw;
+  vec[(wave * 8 + 1) * 64 + lane] = gNb;
+  if constexpr (HEAD == 1) {
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo) vec[(wave * 8 + 2 + bo) * 64 + lane] = quad_sum16(gBh[bo]);
+  } else {
+    vec[(wave * 8 + 2) * 64 + lane] = gWc;
+    const float sdv = wave_sum_f(gBh[0]);
+    if (lane == 0) vec[(wave * 8 + 3) * 64] = sdv;
+  }
+  {
+    const float l0 = wave_sum_f(lacc[0]), l1 = wave_sum_f(lacc[1]), l2 = wave_sum_f(lacc[2]);
+    if (lane == 0) { vec[(wave * 8 + 4) * 64 + 0] = l0; vec[(wave * 8 + 4) * 64 + 1] = l1; vec[(wave * 8 + 4) * 64 + 2] = l2; }
+  }
+  __syncthreads();
+  float *slab = p.slabs + (size_t)bid * p.slab_stride + p.slab_col0;
+  if constexpr (HEAD == 1) {
+    for (int e = threadIdx.x; e < NBH * 4 * 256; e += G16_THREADS) {
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < G16_WAVES; ++w) s += red[w * NBH * 4 * 256 + e];
+      const int blk = e >> 8, ln = (e >> 2) & 63, i = e & 3;
+      const int a = 16 * (blk >> 2) + 4 * (ln >> 4) + i, k = 16 * (blk & 3) + (ln & 15);
+      if (a < A) slab[o.wh + a * HID + k] = s;
+    }
+  }
+  if (threadIdx.x < 4 * 64) {
+    const int which = threadIdx.x >> 6, k = threadIdx.x & 63;    // 0: rn_w, 1: rn_b, 2: head vector 0, 3: head vector 1
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < G16_WAVES; ++w) s += vec[(w * 8 + which) * 64 + k];
+    if (which == 0) slab[o.rn_w + k] = s;
+    else if (which == 1) slab[o.rn_b + k] = s;
+    else if (HEAD == 1) {
+      const int a = 16 * (which - 2) + k;
+      if (k < 16 && which - 2 < NBH && a < A) slab[o.bh + a] = s;
+    } else if (which == 2) slab[o.wh + k] = s;
+    else if (k == 0) slab[o.bh] = s;
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = 0.0;
+      if (k < 3) for (int w = 0; w < G16_WAVES; ++w) v += (double)vec[(w * 8 + 4) * 64 + k];
+      p.partials[(size_t)bid * 4 + k] = v;
+    }
+  }
+}
+
+template <int HEAD, int NBH, bool XBLK>
+__global__ __launch_bounds__(G16_THREADS, 2) void gru16_fwd_kernel(Gru16Args a) {
+  extern __shared__ __align__(16) float lds[];
+  gru16_fwd_body<HEAD, NBH, XBLK>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// ================================================================================================================================
+// backward recurrence + d x
+// ================================================================================================================================
+template <bool DXBLK>
+__device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, const int bid, const int nb) {
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  float *WHT = lds, *WIT = lds + G16_NG * HID;                    // W_hh^T, W_ih^T: out blocks over k (4), k-steps over the 192 gate rows (12)
+  stage_frag_T<6>(WHT, p.params + o.gru_whh, G16_NG, HID);
+  stage_frag_T<6>(WIT, p.params + o.gru_wih, G16_NG, HID);
+  __syncthreads();
+  const int n_ct = (p.Nc + 15) >> 4;
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t CS = (int64_t)p.L * n_ct * 1024;
+  for (int tile = bid * G16_WAVES + wave; tile < n_ct; tile += nb * G16_WAVES) {
+    const int c = tile * 16 + n;
+    const bool ok = c < p.Nc;
+    const int cc = ok ? c : 0;
+    f32x4 carry[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) carry[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = p.L - 1; t >= 0; --t) {
+      // (compiler fence: without it hipcc hoists the NEXT step's 24 loads above this step's MFMA phase — 96 more live registers,
+      // 124 of them spilled; the partner wave of the SIMD covers the load latency instead)
+      asm volatile("" ::: "memory");
+      const int64_t col = (int64_t)t * p.Nc + cc;
+      const int64_t brow = p.rows ? (int64_t)p.rows[col] : col;
+      float *sb = p.scratch + ((int64_t)(t * n_ct + tile) * 4) * 256 + lane * 4;
+      f32x4 dh[4], hm[4], gr[4], gz[4], gn[4], ghn[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        dh[b] = ld4(sb + C_DH * CS + b * 256);
+        gz[b] = ld4(sb + C_Z * CS + b * 256);
+        gn[b] = ld4(sb + C_N * CS + b * 256);
+        gr[b] = ld4(sb + C_R * CS + b * 256);
+        ghn[b] = ld4(sb + C_GHN * CS + b * 256);
+        hm[b] = ld4(sb + C_HM * CS + b * 256);
+      }
+      float mk = p.masks[brow];
+      mk = ok ? mk : 0.f;
+      // d gates, IN PLACE (gr <- d pre_r, hm <- d pre_z, gn <- d pre_n = d gi_n, ghn <- d gh_n; dh <- d h_t + carry): the register
+      // file holds exactly the six loaded vectors.  Dead sequences: d h = 0 and carry = 0, so every product below is 0.
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float dhh = (ok ? dh[b][i] : 0.f) + carry[b][i], zz = gz[b][i], nn = gn[b][i], rr = gr[b][i];
+          dh[b][i] = dhh;
+          const float dn_pre = dhh * (1.f - zz) * (1.f - nn * nn);
+          gn[b][i] = dn_pre;
+          gr[b][i] = dn_pre * ghn[b][i] * rr * (1.f - rr);
+          ghn[b][i] = dn_pre * rr;
+          hm[b][i] = dhh * (hm[b][i] - nn) * zz * (1.f - zz);
+        }
+        st4(sb + C_R * CS + b * 256, gr[b]);
+        st4(sb + C_Z * CS + b * 256, hm[b]);
+        st4(sb + C_N * CS + b * 256, gn[b]);
+        st4(sb + C_GHN * CS + b * 256, ghn[b]);
+      }
+      // carry: W_hh^T [d_r, d_z, d_hn]; d x: W_ih^T [d_r, d_z, d_n] — two independent four-accumulator sets
+      f32x4 dhm[4], dx[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) { dhm[b] = f32x4{0.f, 0.f, 0.f, 0.f}; dx[b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      const float *bh = WHT + lane * 4, *bi = WIT + lane * 4;
+#pragma unroll
+      for (int gate = 0; gate < 3; ++gate) {
+        const f32x4 (&vh)[4] = gate == 0 ? gr : (gate == 1 ? hm : ghn);
+        const f32x4 (&vi)[4] = gate == 0 ? gr : (gate == 1 ? hm : gn);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          f32x4 ah[4], ai[4];
+#pragma unroll
+          for (int bo = 0; bo < 4; ++bo) {
+            ah[bo] = ld4(bh + (bo * 12 + gate * 4 + b) * 256);
+            ai[bo] = ld4(bi + (bo * 12 + gate * 4 + b) * 256);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) dhm[bo] = mfma16(ah[bo][i], vh[b][i], dhm[bo]);
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) dx[bo] = mfma16(ai[bo][i], vi[b][i], dx[bo]);
+          }
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if constexpr (DXBLK) st4(sb + C_DH * CS + b * 256, dx[b]);
+        else if (ok) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) p.dxT[(int64_t)(16 * b + 4 * q + i) * B + col] = dx[b][i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) carry[b][i] = (dhm[b][i] + dh[b][i] * gz[b][i]) * mk;
+      }
+    }
+  }
+}
+
+template <bool DXBLK>
+__global__ __launch_bounds__(G16_THREADS, 2) void gru16_bwd_kernel(Gru16Args a) {
+  extern __shared__ __align__(16) float lds[];
+  gru16_bwd_body<DXBLK>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// ================================================================================================================================
+// weight gradients: workgroup = 2 sets of 4 roles; role = (matrix ih | hh) x (gate rows 0..95 | 96..191); a set walks row tiles
+// ================================================================================================================================
+struct Gru16WgArgs {
+  NetOff off;
+  const float *x;
+  int x_blocked;
+  const float *scratch;
+  int L, Nc;
+  float *slabs;
+  int64_t slab_stride, slab_col0;
+};
+#define WG16_AS 100      // row stride of the d-gate tile [16][96 (+4)]: 100 = 4 mod 8, transposed reads conflict-free (as RS16)
+
+template <bool XBLK>
+__global__ __launch_bounds__(G16_THREADS, 2) void gru16_wgrad_kernel(Gru16WgArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int set = wave >> 2, role = wave & 3, mat = role >> 1, gh = role & 1;
+  float *Ua = lds + wave * (16 * WG16_AS + 16 * RS16), *Ub = Ua + 16 * WG16_AS;
+  const int n_ct = (p.Nc + 15) >> 4;
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t CS = (int64_t)p.L * n_ct * 1024;
+  const int n_rt = p.L * n_ct;
+  f32x4 acc[6][4];
+  float gb[6];
+#pragma unroll
+  for (int bf = 0; bf < 6; ++bf) {
+    gb[bf] = 0.f;
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) acc[bf][bk] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // gate-row block g = 6 gh + bf (0..11): component of its values and block inside the component
+  const float *srcA[6];
+#pragma unroll
+  for (int bf = 0; bf < 6; ++bf) {
+    const int g = 6 * gh + bf;
+    const int comp = g < 4 ? C_R : (g < 8 ? C_Z : (mat ? C_GHN : C_N));
+    srcA[bf] = p.scratch + comp * CS + (g & 3) * 256 + lane * 4;
+  }
+  const float *srcB = mat ? p.scratch + C_HM * CS + lane * 4 : p.x + lane * 4;
+  const int stride = gridDim.x * 2;
+  int rt = blockIdx.x * 2 + set;
+  f32x4 va[6], vb[4];
+  auto load_tile = [&](int r) {
+    const int rr = min(r, n_rt - 1);
+    const int64_t off = (int64_t)rr * 1024;
+#pragma unroll
+    for (int bf = 0; bf < 6; ++bf) va[bf] = ld4(srcA[bf] + off);
+    if (mat || XBLK) {
+#pragma unroll
+      for (int bk = 0; bk < 4; ++bk) vb[bk] = ld4(srcB + off + bk * 256);
+    } else {
+      const int t = rr / n_ct, c = min((rr - t * n_ct) * 16 + n, p.Nc - 1);
+      const int64_t col = (int64_t)t * p.Nc + c;
+#pragma unroll
+      for (int bk = 0; bk < 4; ++bk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) vb[bk][i] = p.x[(int64_t)(16 * bk + 4 * q + i) * B + col];
+    }
+  };
+  load_tile(rt);
+  for (; rt < n_rt; rt += stride) {
+#pragma unroll
+    for (int bf = 0; bf < 6; ++bf) st4(Ua + n * WG16_AS + 16 * bf + 4 * q, va[bf]);
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) st4(Ub + n * RS16 + 16 * bk + 4 * q, vb[bk]);
+    load_tile(rt + stride);                                     // next tile: in flight under this tile's products
+    wave_lds_sync();
+    dw_accum16<6, 4>(acc, gb, Ua, WG16_AS, Ub, RS16, n, q);
+    wave_lds_sync();
+  }
+  // ---- set 1 hands its sums to set 0 through LDS; set 0 writes the workgroup's slab row ----
+  __syncthreads();
+  float *red = lds + role * (26 * 256);                          // [24 accumulator blocks][256] | 6 bias-partial rows of 64
+  if (set == 1) {
+#pragma unroll
+    for (int bf = 0; bf < 6; ++bf) {
+#pragma unroll
+      for (int bk = 0; bk < 4; ++bk) st4(red + ((bf * 4 + bk) * 64 + lane) * 4, acc[bf][bk]);
+      red[24 * 256 + bf * 64 + lane] = gb[bf];
+    }
+  }
+  __syncthreads();
+  if (set == 1) return;
+  float *slab = p.slabs + (size_t)blockIdx.x * p.slab_stride + p.slab_col0;
+  const int woff = mat ? p.off.gru_whh : p.off.gru_wih, boff = mat ? p.off.gru_bhh : p.off.gru_bih;
+#pragma unroll
+  for (int bf = 0; bf < 6; ++bf) {
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) {
+      const f32x4 o2 = ld4(red + ((bf * 4 + bk) * 64 + lane) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) slab[woff + (96 * gh + 16 * bf + 4 * q + i) * HID + 16 * bk + n] = acc[bf][bk][i] + o2[i];
+    }
+    const float bsum = quad_sum16(gb[bf] + red[24 * 256 + bf * 64 + lane]);
+    if (q == 0) slab[boff + 96 * gh + 16 * bf + n] = bsum;
+  }
+}
+
+// ================================================================================================================================
+// host
+// ================================================================================================================================
+#ifndef NUM_CU
+#define NUM_CU 256
+#endif
+static int check_rec16(const mappo_net_desc *d, const char *who) {
+  MAPPO_REQUIRE(d && d->recurrent, "%s: needs a recurrent network descriptor", who);
+  MAPPO_REQUIRE(d->hidden == HID, "%s: hidden_size %d unsupported", who, d->hidden);
+  MAPPO_REQUIRE(d->out_dim >= 1 && d->out_dim <= MAPPO_MAX_ACTIONS, "%s: out_dim %d", who, d->out_dim);
+  return MAPPO_OK;
+}
+static int seq_grid(int Nc) {
+  const int n_ct = (Nc + 15) / 16, want = (n_ct + G16_WAVES - 1) / G16_WAVES;
+  return want < NUM_CU ? want : NUM_CU;
+}
+static int wg_grid(int L, int Nc) {
+  const int n_rt = L * ((Nc + 15) / 16), want = (n_rt + 1) / 2;
+  return want < NUM_CU ? want : NUM_CU;
+}
+
+extern "C" int64_t mappo_gru16_scratch_floats(int32_t L, int32_t Nc) { return (int64_t)G16_COMPS * L * ((Nc + 15) / 16) * 1024; }
+extern "C" int64_t mappo_gru16_blocked_floats(int32_t L, int32_t Nc) { return (int64_t)L * ((Nc + 15) / 16) * 1024; }
+extern "C" int32_t mappo_gru16_slabs(int32_t L, int32_t Nc) {
+  const int a = seq_grid(Nc), b = wg_grid(L, Nc);
+  return a > b ? a : b;
+}
+
+template <int HEAD, int NBH, bool XBLK>
+static int fwd16_launch(const Gru16Args &a, dim3 grid, hipStream_t st) {
+  typedef F16Lds<HEAD, NBH> M;
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_fwd_kernel<HEAD, NBH, XBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+  if (e_ != hipSuccess) { mappo_set_error("gru16_forward_loss: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  hipLaunchKernelGGL((gru16_fwd_kernel<HEAD, NBH, XBLK>), grid, dim3(G16_THREADS), (size_t)M::TOTAL * sizeof(float), st, a);
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_gru16_forward_loss(const float *params, const mappo_net_desc *desc, const float *x, int32_t x_blocked, const float *h0,
+                                        const int32_t *h0_rows, const float *masks, const int32_t *rows, int32_t L, int32_t Nc, int32_t head,
+                                        const float *avail, const float *actions, const float *old_logp, const float *adv, const float *active,
+                                        const float *v_old, const float *returns, const float *vn_state, const double *mb_moments,
+                                        const mappo_ppo_cfg *cfg, float *scratch, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                                        double *partials, mappo_stream_t stream) {
+  if (int rc = check_rec16(desc, "gru16_forward_loss")) return rc;
+  MAPPO_REQUIRE(params && x && h0 && masks && scratch && slabs && partials && mb_moments && cfg && active && L > 0 && Nc > 0,
+                "gru16_forward_loss: bad arguments");
+  MAPPO_REQUIRE(head == 1 || head == 2, "gru16_forward_loss: head %d", head);
+  MAPPO_REQUIRE(head == 1 ? (actions && old_logp && adv) : (v_old && returns && desc->out_dim == 1), "gru16_forward_loss: loss inputs");
+  MAPPO_REQUIRE(!cfg->use_valuenorm || head == 1 || vn_state, "gru16_forward_loss: use_valuenorm needs vn_state");
+  MAPPO_CLEAR_STICKY();
+  Gru16Args a = {};
+  a.params = params; a.off = net_offsets(*desc); a.x = x; a.x_blocked = x_blocked; a.h0 = h0; a.h0_rows = h0_rows; a.masks = masks; a.rows = rows;
+  a.L = L; a.Nc = Nc; a.A = desc->out_dim; a.scratch = scratch; a.avail = avail; a.actions = actions; a.old_logp = old_logp; a.adv = adv;
+  a.active = active; a.v_old = v_old; a.returns = returns; a.vn_state = vn_state; a.mb_moments = mb_moments; a.cfg = *cfg;
+  a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0; a.partials = partials;
+  MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru16_forward_loss: slab column range");
+  const dim3 grid((unsigned)seq_grid(Nc));
+  const hipStream_t st = as_stream(stream);
+  int rc;
+  if (head == 2) rc = x_blocked ? fwd16_launch<2, 1, true>(a, grid, st) : fwd16_launch<2, 1, false>(a, grid, st);
+  else if (a.A <= 16) rc = x_blocked ? fwd16_launch<1, 1, true>(a, grid, st) : fwd16_launch<1, 1, false>(a, grid, st);
+  else rc = x_blocked ? fwd16_launch<1, 2, true>(a, grid, st) : fwd16_launch<1, 2, false>(a, grid, st);
+  if (rc) return rc;
+  MAPPO_CHECK_LAUNCH("gru16_forward_loss");
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_gru16_backward(const float *params, const mappo_net_desc *desc, const float *masks, const int32_t *rows, int32_t L,
+                                    int32_t Nc, float *scratch, float *dxT, mappo_stream_t stream) {
+  if (int rc = check_rec16(desc, "gru16_backward")) return rc;
+  MAPPO_REQUIRE(params && masks && scratch && L > 0 && Nc > 0, "gru16_backward: bad arguments");
+  MAPPO_CLEAR_STICKY();
+  Gru16Args a = {};
+  a.params = params; a.off = net_offsets(*desc); a.masks = masks; a.rows = rows; a.L = L; a.Nc = Nc; a.scratch = scratch; a.dxT = dxT;
+  const dim3 grid((unsigned)seq_grid(Nc));
+  const size_t lds_bytes = (size_t)2 * G16_NG * HID * sizeof(float);
+  if (dxT) {
+    static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e_ != hipSuccess) { mappo_set_error("gru16_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    hipLaunchKernelGGL(gru16_bwd_kernel<false>, grid, dim3(G16_THREADS), lds_bytes, as_stream(stream), a);
+  } else {
+    static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e_ != hipSuccess) { mappo_set_error("gru16_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    hipLaunchKernelGGL(gru16_bwd_kernel<true>, grid, dim3(G16_THREADS), lds_bytes, as_stream(stream), a);
+  }
+  MAPPO_CHECK_LAUNCH("gru16_backward");
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_gru16_wgrad(const mappo_net_desc *desc, const float *x, int32_t x_blocked, const float *scratch, int32_t L, int32_t Nc,
+                                 float *slabs, int64_t slab_stride, int64_t slab_col0, mappo_stream_t stream) {
+  if (int rc = check_rec16(desc, "gru16_wgrad")) return rc;
+  MAPPO_REQUIRE(x && scratch && slabs && L > 0 && Nc > 0, "gru16_wgrad: bad arguments");
+  MAPPO_CLEAR_STICKY();
+  Gru16WgArgs a = {};
+  a.off = net_offsets(*desc); a.x = x; a.x_blocked = x_blocked; a.scratch = scratch; a.L = L; a.Nc = Nc;
+  a.slabs = slabs; a.slab_stride = slab_stride; a.slab_col0 = slab_col0;
+  MAPPO_REQUIRE(slab_col0 >= 0 && slab_col0 + a.off.total <= slab_stride, "gru16_wgrad: slab column range");
+  const dim3 grid((unsigned)wg_grid(L, Nc));
+  // per-wave operand tiles; the epilogue's hand-over buffer (4 roles x 26 blocks of 256 floats) overlays them
+  const size_t tiles = (size_t)G16_WAVES * (16 * WG16_AS + 16 * RS16), epi = (size_t)4 * 26 * 256;
+  const size_t lds_bytes = (tiles > epi ? tiles : epi) * sizeof(float);
+  if (x_blocked) {
+    static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e_ != hipSuccess) { mappo_set_error("gru16_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    hipLaunchKernelGGL(gru16_wgrad_kernel<true>, grid, dim3(G16_THREADS), lds_bytes, as_stream(stream), a);
+  } else {
+    static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    if (e_ != hipSuccess) { mappo_set_error("gru16_wgrad: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    hipLaunchKernelGGL(gru16_wgrad_kernel<false>, grid, dim3(G16_THREADS), lds_bytes, as_stream(stream), a);
+  }
+  MAPPO_CHECK_LAUNCH("gru16_wgrad");
+  return MAPPO_OK;
+}

@@ -135,7 +135,8 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), j = lane & 15, q = lane >> 4;
   const int D = p.desc.in_dim, A = p.desc.out_dim;
-  const int64_t n_tiles = (p.B + 15) / 16;
+  const int seq_nc = MODE == 3 ? p.seq_nc : 0, n_ct = (seq_nc + 15) >> 4;       // MODE 3: sequence tiling, blocked trunk output
+  const int64_t n_tiles = MODE == 3 ? (p.B / seq_nc) * n_ct : (p.B + 15) / 16;
   const bool fnorm = p.desc.use_feature_norm != 0;
   float *tZ = lds + wave * 16 * TP;                              // [16][TP] logits of this wave's samples (MODE 1)
   int64_t tile = (int64_t)bid * n_waves + wave;
@@ -144,7 +145,7 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
   // ---- weights and vectors of this lane (issued before the first wait) ----
   Trunk16R<LN> tw;
   trunk16r_load<LN>(tw, P, o, p.desc, j, q);
-  constexpr int NBH = MODE == 1 ? 2 : (MODE == 0 ? 1 : 0);       // head blocks of 16 outputs (critic: row 0 only)
+  constexpr int NBH = MODE == 1 ? 2 : (MODE == 0 ? 1 : 0);       // head blocks of 16 outputs (critic: row 0 only; MODE 2 / 3: no head)
   f32x4 wh[NBH > 0 ? NBH : 1][4];
   f32x4 bhv[NBH > 0 ? NBH : 1];
   if constexpr (NBH > 0) {
@@ -161,8 +162,14 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
     }
   }
   for (; tile < n_tiles; tile += (int64_t)nb * n_waves) {
-    const int64_t i = tile * 16 + j;
-    const bool ok = i < p.B;
+    int64_t i = tile * 16 + j;
+    bool ok = i < p.B;
+    if constexpr (MODE == 3) {                                    // (t, 16 sequences) tiles; every lane computes a real row
+      const int64_t t = tile / n_ct;
+      const int c = (int)(tile - t * n_ct) * 16 + j;
+      i = t * seq_nc + (c < seq_nc ? c : 0);
+      ok = true;
+    }
     const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
     const int64_t off = p.x_M ? (row / p.x_M) * p.x_sn + (row % p.x_M) * p.x_sm : row * D;
     f32x4 x[4];
@@ -173,7 +180,11 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
     f32x4 h[4];
     trunk16r_apply<RELU, LN>(tw, x, h, D, ok, fnorm, q);
     // ---- head ----
-    if constexpr (MODE == 2) {
+    if constexpr (MODE == 3) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        *reinterpret_cast<float4 *>(p.out + (tile * 4 + b) * 256 + lane * 4) = make_float4(h[b][0], h[b][1], h[b][2], h[b][3]);
+    } else if constexpr (MODE == 2) {
       if (ok) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)

@@ -596,6 +596,11 @@ struct FwdArgs {
   // env's output read in place (fused rollout step); x_M == 0: contiguous rows x[i * in_dim]
   int64_t x_sn, x_sm;
   int x_M;
+  // MODE 3 (features16_seq_kernel) only: seq_nc > 0 = sequence tiling (recurrent training): B = L * seq_nc rows in time-major minibatch order are tiled per
+  // (t, 16 sequences) — tile i = (t = i / n_ct, j = i % n_ct), n_ct = ceil(seq_nc / 16) — and the trunk output is written BLOCKED,
+  // out[(i * 4 + b) * 256 + 4 * lane + r] = feature 16 b + 4 q + r of sequence 16 j + n (gru_train16.hip); lanes beyond seq_nc
+  // hold the features of sequence 0 (finite values that only ever meet zero gradients)
+  int seq_nc;
 };
 
 // XW: 0 = in_dim <= 32, 1 = in_dim <= 64 (rows prefetched into registers), 2 = in_dim > 64 (K-chunked layer 1)
@@ -709,6 +714,12 @@ __global__ __launch_bounds__(256, 1) void features16_kernel(FwdArgs a) {
   extern __shared__ __align__(16) float lds[];
   forward16r_body<RELU, LN, 2>(a, lds, blockIdx.x, gridDim.x);
 }
+// the same for the sequence-tiled minibatch of the recurrent training pass: blocked output (FwdArgs::seq_nc, gru_train16.hip)
+template <bool RELU, int LN>
+__global__ __launch_bounds__(256, 1) void features16_seq_kernel(FwdArgs a) {
+  extern __shared__ __align__(16) float lds[];
+  forward16r_body<RELU, LN, 3>(a, lds, blockIdx.x, gridDim.x);
+}
 template <bool RELU, int LN>
 __global__ __launch_bounds__(256, 1) void features16_dual_kernel(FwdArgs a, FwdArgs c, int nA) {
   extern __shared__ __align__(16) float lds[];
@@ -764,6 +775,7 @@ struct UpdArgs {
   int red_base;              // start of that range (b1 for wide inputs: W1 / feature-norm grads come from wide_l1_bwd_kernel)
   float *wide_ws;            // wide inputs: [64][B] dz1 (feature-major) | mean0[B] | rstd0[B]
   const float *dHT;          // HEAD 3: gradient w.r.t. the trunk output, feature-major [64][B]
+  int seq_nc;                // HEAD 3, in_dim <= 64: > 0 = sequence tiling (see FwdArgs::seq_nc) and dHT is BLOCKED per tile
   // HEAD 0
   const float *dout;
   // HEAD 1 / 2 (buffer-order arrays, indexed by rows)
@@ -1624,6 +1636,12 @@ template <bool R, int L>
 static int features16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const FwdArgs &a) {
   static const hipError_t e_ = hipFuncSetAttribute((const void *)features16_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
   if (e_ != hipSuccess) { mappo_set_error("mlp_features: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  if (a.seq_nc > 0) {
+    static const hipError_t es_ = hipFuncSetAttribute((const void *)features16_seq_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
+    if (es_ != hipSuccess) { mappo_set_error("mlp_features_seq: hipFuncSetAttribute: %s", hipGetErrorString(es_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+    hipLaunchKernelGGL((features16_seq_kernel<R, L>), grid, block, lds_bytes, st, a);
+    return MAPPO_OK;
+  }
   hipLaunchKernelGGL((features16_kernel<R, L>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1631,7 +1649,7 @@ static int features16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_
 int launch_features16(const FwdArgs &a_in, hipStream_t st) {
   MAPPO_CLEAR_STICKY();
   FwdArgs a = a_in;
-  const int64_t n_tiles = (a.B + 15) / 16;
+  const int64_t n_tiles = a.seq_nc > 0 ? (a.B / a.seq_nc) * ((a.seq_nc + 15) / 16) : (a.B + 15) / 16;
   const int nw = fit_waves(a.desc, n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1));
   a.off = net_offsets(a.desc); a.map = lds_map(a.desc, nw);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
@@ -1867,6 +1885,18 @@ extern "C" int mappo_mlp_features(const float *params, const mappo_net_desc *des
   return launch_forward<2>(a, as_stream(stream), "mlp_features");
 }
 
+// recurrent training (gru_train16.hip): trunk features of the time-major [L][Nc] minibatch, tiled per (t, 16 sequences) and written
+// blocked per tile — the B operand layout of the GRU kernels, one contiguous KiB per wave store
+extern "C" int mappo_mlp_features_seq(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
+                                      int32_t L, int32_t Nc, float *out_blocked, mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(desc, "mlp_features_seq")) return rc;
+  MAPPO_REQUIRE(params && x && out_blocked && L > 0 && Nc > 0, "mlp_features_seq: bad arguments");
+  MAPPO_REQUIRE(desc->in_dim <= MAXD, "mlp_features_seq: in_dim %d > %d takes mappo_mlp_features (feature-major)", desc->in_dim, MAXD);
+  FwdArgs a = {};
+  a.params = params; a.x = x; a.rows = rows; a.out = out_blocked; a.desc = *desc; a.B = (int64_t)L * Nc; a.seq_nc = Nc;
+  return launch_features16(a, as_stream(stream));
+}
+
 extern "C" int mappo_actor_act(const float *params, const mappo_net_desc *desc, const float *obs, const float *avail,
                                int64_t B, int32_t deterministic, uint64_t seed, uint64_t counter,
                                const uint64_t *counter_dev, float *actions, float *logp, mappo_stream_t stream) {
@@ -2091,6 +2121,20 @@ extern "C" int mappo_trunk_backward(const float *params, const mappo_net_desc *d
   a.params = params; a.x = x; a.rows = rows; a.dHT = dHT; a.slabs = slabs; a.slab_stride = slab_stride;
   a.slab_col0 = slab_col0; a.desc = *desc; a.B = B; a.wide_ws = wide_ws;
   return launch_update<3>(a, as_stream(stream), "trunk_backward");
+}
+
+// the same for the sequence-tiled minibatch of the recurrent training pass: d(trunk output) arrives BLOCKED per (t, 16 sequences)
+// tile (the d x component gru16_bwd_kernel leaves in its scratch); in_dim <= 64
+extern "C" int mappo_trunk_backward_seq(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
+                                        int32_t L, int32_t Nc, const float *dx_blocked, float *slabs, int64_t slab_stride,
+                                        int64_t slab_col0, mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(desc, "trunk_backward_seq")) return rc;
+  MAPPO_REQUIRE(params && x && dx_blocked && slabs && L > 0 && Nc > 0, "trunk_backward_seq: bad arguments");
+  MAPPO_REQUIRE(desc->in_dim <= MAXD && desc->layer_N <= 1, "trunk_backward_seq: in_dim %d / layer_N %d take mappo_trunk_backward", desc->in_dim, desc->layer_N);
+  UpdArgs a = {};
+  a.params = params; a.x = x; a.rows = rows; a.dHT = dx_blocked; a.slabs = slabs; a.slab_stride = slab_stride;
+  a.slab_col0 = slab_col0; a.desc = *desc; a.B = (int64_t)L * Nc; a.seq_nc = Nc;
+  return launch_update<3>(a, as_stream(stream), "trunk_backward_seq");
 }
 
 extern "C" int64_t mappo_update_partials_bytes(void) { return (int64_t)NUM_CU * 4 * sizeof(double); }

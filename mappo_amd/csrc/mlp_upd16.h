@@ -218,10 +218,17 @@ template <int HEAD, bool WIDE>
 __device__ __forceinline__ void prefetch16(Prefetch16<WIDE> &pf, const UpdArgs &p, int64_t tile, int64_t n_tiles, int D, int C, int A,
                                            int lane, int n, int q) {
   constexpr int NV = WIDE ? 16 : 8;
-  const int64_t base = tile * 16;
-  const int nv = (tile < n_tiles) ? (int)min((int64_t)16, p.B - base) : 0;
+  int64_t base = tile * 16;
+  int nv = (tile < n_tiles) ? (int)min((int64_t)16, p.B - base) : 0;
+  if (HEAD == 3 && p.seq_nc > 0 && tile < n_tiles) {               // (t, 16 sequences) tiles of a time-major [L][seq_nc] minibatch
+    const int n_ct = (p.seq_nc + 15) >> 4;
+    const int64_t t = tile / n_ct;
+    const int j0 = (int)(tile - t * n_ct) * 16;
+    base = t * p.seq_nc + j0;
+    nv = min(16, p.seq_nc - j0);
+  }
   pf.n_valid = nv;
-  pf.flat = p.rows == nullptr && nv == 16 && (((uintptr_t)p.x) & 15) == 0;
+  pf.flat = p.rows == nullptr && nv == 16 && (((uintptr_t)(p.x + base * D)) & 15) == 0;
   pf.f0 = pf.f1 = pf.f2 = pf.f3 = 0.f;
   pf.dead = 0u;
   if (nv == 0) return;                                           // no such tile (wave-uniform)
@@ -416,7 +423,8 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   const int D = p.desc.in_dim, A = p.desc.out_dim, C = (D + 3) >> 2;
   const bool fnorm = p.desc.use_feature_norm != 0;
   const float inv_D = 1.0f / (float)D;
-  const int64_t n_tiles = (p.B + 15) / 16;
+  const bool seq = HEAD == 3 && !XL1 && p.seq_nc > 0;       // sequence tiling + blocked d(trunk output) (recurrent training, gru_train16.hip)
+  const int64_t n_tiles = seq ? (p.B / p.seq_nc) * ((p.seq_nc + 15) >> 4) : (p.B + 15) / 16;
   const int64_t tile_stride = (int64_t)nb * n_waves;
   const int64_t tile0 = (int64_t)wave * nb + bid;          // remainder of the last round spreads over all CUs
   Prefetch16<WIDE> pf;
@@ -579,11 +587,17 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   constexpr bool DH_AHEAD = HEAD == 3 && (XL1 || !WIDE);
   f32x4 dh_next[DH_AHEAD ? 4 : 1];
   if constexpr (DH_AHEAD) {
-    const float *dcol = p.dHT + min(tile0 * 16 + n, p.B - 1);
+    if (seq) {
+      const float *db = p.dHT + min(tile0, n_tiles - 1) * 1024 + lane * 4;
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < 4; ++b) dh_next[b] = ld4(db + b * 256);
+    } else {
+      const float *dcol = p.dHT + min(tile0 * 16 + n, p.B - 1);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) dh_next[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dh_next[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+    }
   }
   for (int64_t tile = tile0; tile < n_tiles; tile += tile_stride) {
     const int n_valid = pf.n_valid;
@@ -670,11 +684,21 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       if constexpr (DH_AHEAD) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) dh[b] = dh_next[b];
-        const float *dcol = p.dHT + min((tile + tile_stride) * 16 + n, p.B - 1);
+        if (seq) {
+          const float *db = p.dHT + min(tile + tile_stride, n_tiles - 1) * 1024 + lane * 4;
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+          for (int b = 0; b < 4; ++b) dh_next[b] = ld4(db + b * 256);
+        } else {
+          const float *dcol = p.dHT + min((tile + tile_stride) * 16 + n, p.B - 1);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dh_next[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+          for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dh_next[b][i] = dcol[(int64_t)(16 * b + 4 * q + i) * p.B];
+        }
+      } else if (seq) {
+        const float *db = p.dHT + tile * 1024 + lane * 4;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) dh[b] = ld4(db + b * 256);
       } else {
         const float *dcol = p.dHT + min(tile * 16 + n, p.B - 1);
 #pragma unroll

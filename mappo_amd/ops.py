@@ -435,6 +435,55 @@ def trunk_backward(params, desc, x, rows, B, dxT, slabs, slab_stride, slab_col0)
     _wide(desc, x, rows, B, slabs, slab_stride, slab_col0, params, ws, PRODUCER_TRUNK_BACKWARD)
 
 
+# ---- K9 training pass on 16-sequence tiles (gru_train16.hip) ---------------------------------------
+def gru16_scratch_floats(L, Nc):
+    return int(_lib.load().mappo_gru16_scratch_floats(int(L), int(Nc)))
+
+
+def gru16_blocked_floats(L, Nc):
+    return int(_lib.load().mappo_gru16_blocked_floats(int(L), int(Nc)))
+
+
+def gru16_slabs(L, Nc):
+    return int(_lib.load().mappo_gru16_slabs(int(L), int(Nc)))
+
+
+def mlp_features_seq(params, desc, x, rows, L, Nc, out_blocked):
+    rc = _lib.load().mappo_mlp_features_seq(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc),
+                                            _ptr(out_blocked), _stream())
+    _lib.check(rc, "mappo_mlp_features_seq")
+
+
+def gru16_forward_loss(params, desc, x, x_blocked, h0, h0_rows, masks, rows, L, Nc, head, avail, actions, old_logp, adv, active, v_old,
+                       returns, vn_state, mb_moments, cfg, scratch, slabs, slab_stride, slab_col0, partials):
+    o = lambda t: _ptr(t, allow_none=True)
+    rc = _lib.load().mappo_gru16_forward_loss(_ptr(params), C.byref(desc), _ptr(x), int(bool(x_blocked)), _ptr(h0),
+                                              _ptr(h0_rows, torch.int32, allow_none=True), _ptr(masks),
+                                              _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc), int(head), o(avail), o(actions),
+                                              o(old_logp), o(adv), _ptr(active), o(v_old), o(returns), o(vn_state),
+                                              _ptr(mb_moments, torch.float64), C.byref(cfg), _ptr(scratch), _ptr(slabs), int(slab_stride),
+                                              int(slab_col0), _ptr(partials, torch.float64), _stream())
+    _lib.check(rc, "mappo_gru16_forward_loss")
+
+
+def gru16_backward(params, desc, masks, rows, L, Nc, scratch, dxT=None):
+    rc = _lib.load().mappo_gru16_backward(_ptr(params), C.byref(desc), _ptr(masks), _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc),
+                                          _ptr(scratch), _ptr(dxT, allow_none=True), _stream())
+    _lib.check(rc, "mappo_gru16_backward")
+
+
+def gru16_wgrad(desc, x, x_blocked, scratch, L, Nc, slabs, slab_stride, slab_col0):
+    rc = _lib.load().mappo_gru16_wgrad(C.byref(desc), _ptr(x), int(bool(x_blocked)), _ptr(scratch), int(L), int(Nc), _ptr(slabs),
+                                       int(slab_stride), int(slab_col0), _stream())
+    _lib.check(rc, "mappo_gru16_wgrad")
+
+
+def trunk_backward_seq(params, desc, x, rows, L, Nc, dx_blocked, slabs, slab_stride, slab_col0):
+    rc = _lib.load().mappo_trunk_backward_seq(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc),
+                                              _ptr(dx_blocked), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+    _lib.check(rc, "mappo_trunk_backward_seq")
+
+
 # ---- K10 / K11 ------------------------------------------------------------------------------------
 def slab_reduce(slabs, n_slabs, slab_stride, P, grad):
     rc = _lib.load().mappo_slab_reduce(_ptr(slabs), int(n_slabs), int(slab_stride), int(P), _ptr(grad), _stream())

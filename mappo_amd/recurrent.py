@@ -37,8 +37,27 @@ class _Scratch:
             self._c[key] = s
         return s
 
+    def get16(self, device, L, Nc, tag, narrow):
+        """Work arrays of the 16-sequence-tile training kernels (gru_train16.hip): the blocked scratch [6][L][n_ct][4][256], the
+        trunk features (blocked for in_dim <= 64, feature-major otherwise) and, for wide inputs, the feature-major d x."""
+        key = ("g16", L, Nc, tag, narrow)
+        s = self._c.get(key)
+        if s is None:
+            f = lambda n: torch.empty(int(n), dtype=torch.float32, device=device)
+            comp = ops.gru16_blocked_floats(L, Nc)
+            scratch = f(ops.gru16_scratch_floats(L, Nc))
+            s = dict(scratch=scratch, dx=scratch[5 * comp:6 * comp])
+            if narrow:
+                s["feat"] = f(comp)
+            else:
+                s["feat"] = torch.empty(H, L * Nc, dtype=torch.float32, device=device)
+                s["dxT"] = torch.empty(H, L * Nc, dtype=torch.float32, device=device)
+            self._c[key] = s
+        return s
+
 
 _scratch = _Scratch()
+_USE_GRU16 = os.environ.get("MAPPO_GRU16", "1") != "0"      # diagnostic switch while the round-2 training kernels still exist
 
 
 def _seq_shape(n_rows, rnn_states):
@@ -147,15 +166,21 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
                 ops.valuenorm_update_n(vn_state, tr._mb_moments, tr.value_normalizer.beta, epochs[1], epochs[2])
     if epochs is not None and tr._use_valuenorm:
         vn_state = epochs[2][epochs[0]]
-    n_trunk, n_bwd, n_wg = ops.mlp_backward_slabs(B), ops.gru_backward_slabs(Nc), ops.gru_wgrad_slabs(L, Nc)
-    n_slabs = max(n_trunk, n_bwd, n_wg)
+    n_trunk = ops.mlp_backward_slabs(B)
+    if _USE_GRU16:
+        n_bwd = ops.gru16_slabs(L, Nc)                         # rows of loss partials / slab rows the 16-sequence-tile kernels may write
+        n_slabs = max(n_trunk, n_bwd)
+    else:
+        n_bwd, n_wg = ops.gru_backward_slabs(Nc), ops.gru_wgrad_slabs(L, Nc)
+        n_slabs = max(n_trunk, n_bwd, n_wg)
     P = pol.n_flat
-    slabs = tr._buf("slabs_rec", (n_slabs, P), zero=True)      # rows a kernel never writes stay zero
+    sfx = "16" if _USE_GRU16 else ""
+    slabs = tr._buf("slabs_rec" + sfx, (n_slabs, P), zero=True)      # rows a kernel never writes stay zero
     if not update_actor and not tr._actor_slabs_clean:
         slabs[:, :pol.seg_bounds[1]].zero_()
     tr._actor_slabs_clean = not update_actor
-    pa = tr._buf("partials_a", (1024,), torch.float64, zero=True)
-    pc = tr._buf("partials_c", (1024,), torch.float64, zero=True)
+    pa = tr._buf("partials_a" + sfx, (1024,), torch.float64, zero=True)
+    pc = tr._buf("partials_c" + sfx, (1024,), torch.float64, zero=True)
     nets = []
     if update_actor:
         nets.append((pol.actor, src["obs"], src["h0_a"], 1, pa, 0, "actor"))
@@ -177,6 +202,26 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
         ops.gru_input_backward(net.flat, net.desc, s["dgiT"], B, s["dxT"])
         ops.gru_wgrad(net.desc, s["featT"], s["gates"], s["dgiT"], s["dghnT"], L, Nc, slabs, P, col0)
         ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
+
+    if _USE_GRU16:
+        def one_net(net, x, h0, head, part, col0, tag):   # noqa: F811 — 16-sequence-tile kernels (gru_train16.hip)
+            narrow = net.desc.in_dim <= 64 and net.desc.layer_N <= 1
+            s = _scratch.get16(dev, L, Nc, tag, narrow)
+            if narrow:
+                ops.mlp_features_seq(net.flat, net.desc, x, rows, L, Nc, s["feat"])
+            else:
+                ops.mlp_features(net.flat, net.desc, x, rows, B, s["feat"])
+            ops.gru16_forward_loss(net.flat, net.desc, s["feat"], narrow, h0, h0_rows, src["masks"], rows, L, Nc, head,
+                                   src["avail"] if head == 1 else None, src["actions"] if head == 1 else None,
+                                   src["old_logp"] if head == 1 else None, src["adv"] if head == 1 else None, src["active"],
+                                   src["v_old"] if head == 2 else None, src["returns"] if head == 2 else None,
+                                   vn_state if head == 2 else None, tr._mb_moments, tr._cfg, s["scratch"], slabs, P, col0, part)
+            ops.gru16_backward(net.flat, net.desc, src["masks"], rows, L, Nc, s["scratch"], None if narrow else s["dxT"])
+            ops.gru16_wgrad(net.desc, s["feat"], narrow, s["scratch"], L, Nc, slabs, P, col0)
+            if narrow:
+                ops.trunk_backward_seq(net.flat, net.desc, x, rows, L, Nc, s["dx"], slabs, P, col0)
+            else:
+                ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
 
     # The sequential GRU kernels occupy one wave per 32 sequences (240 of the chip's 1024 SIMDs at BASELINE config 2), so
     # the two networks' chains run side by side on two streams; they write disjoint slab columns and disjoint partials.

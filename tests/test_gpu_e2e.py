@@ -192,10 +192,10 @@ def test_ppo_update_golden_variants(M, unfused):
         sample = tuple(d[f"sample/{nm}"] for nm in TUPLE)
         for rep in range(2 if fl["two_steps"] else 1):
             out = tr.ppo_update(sample, fl["update_actor"])
-            # north_star: 1e-5 relative on losses.  policy_loss is a mean of O(1) terms of both signs (normalised advantages) that
-            # cancels to ~1e-2: the absolute floor is a few ulp of the TERMS, in the reference's own fp32 sum as much as in ours
+            # north_star: 1e-5 relative on losses.  Measured over the 12 variants (profiles/r03/tolerance_budget_stat_errors.json):
+            # at most 1.0e-7 relative on any of the six statistics — checked at 2e-6, five times inside the target
             _record_stat_errors("ppo_update" + ("_unfused" if unfused else ""), out, d[f"r{rep}/stats"])
-            close(np.array(out, dtype=np.float64), d[f"r{rep}/stats"], 1e-5, 2e-7, f"case {c} stats")
+            close(np.array(out, dtype=np.float64), d[f"r{rep}/stats"], 2e-6, 1e-8, f"case {c} stats")
             for tag, net, opt, seg in (("actor", pol.actor, pol.actor_optimizer, 0), ("critic", pol.critic, pol.critic_optimizer, 1)):
                 ref_sd = sub(g, f"c{c}/r{rep}/{tag}")
                 for k, v in net.state_dict().items():
@@ -263,9 +263,8 @@ def test_train_golden_end_to_end(M, case, unfused):
     ref = dict(zip([str(k) for k in d["info_keys"]], d["info"]))
     _record_stat_errors(f"train_c{case}" + ("_unfused" if unfused else ""), [info[k] for k in STAT_NAMES], [ref[k] for k in STAT_NAMES])
     for k, v in info.items():
-        # averages over ppo_epoch x num_mini_batch updates whose parameters already differ by the Adam steps' rounding (each
-        # step moves a weight by ~lr = 7e-4 with a relative error of ~1e-4 of the step): 3e-5 relative measured at most
-        close(v, ref[k], 5e-5, 2e-7, k)
+        # averages over ppo_epoch x num_mini_batch updates: 8.5e-8 relative measured at most (same file); checked at 2e-6
+        close(v, ref[k], 2e-6, 1e-8, k)
     for tag, net in (("actor1", pol.actor), ("critic1", pol.critic)):
         ref_sd = sub(g, f"c{case}/{tag}")
         for k, v in net.state_dict().items():
