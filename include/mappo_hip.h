@@ -402,11 +402,11 @@ int mappo_mpe_spread_step(double *agent_pos, double *agent_vel, double *landmark
 /* ---- benchmark utility: the synthetic SMAC-shaped vec-env of bench.py / scripts (mappo_amd/envs/synthetic.py), one launch per
  * step.  Not a reference interface (the reference's envs are CPU processes, onpolicy/envs/starcraft2/StarCraft2_Env.py): it only
  * produces data of the SMAC shapes with agents that die and episodes that end.  obs [N][M][D], share_obs [N][M][S] ~ N(0,1);
- * avail [N][M][A] in {0,1}; rewards [N]; dead (state) / dones [N][M] bool bytes; *counter_dev keys the Philox stream (advance
- * it between steps). */
+ * avail [N][M][A] in {0,1}; rewards [N]; dead (state) / dones [N][M] bool bytes; counter_dev [2] = {counter, tickets}:
+ * counter keys the Philox stream and is advanced by the launch itself (last workgroup to finish), tickets must start at 0. */
 int mappo_synth_smac_step(float *obs, float *share_obs, float *avail, float *rewards, uint8_t *dead, uint8_t *dones,
                           int32_t N, int32_t M, int32_t D, int32_t S, int32_t A, float p_death, float p_term,
-                          uint64_t seed, const uint64_t *counter_dev, mappo_stream_t stream);
+                          uint64_t seed, uint64_t *counter_dev /*[2]*/, mappo_stream_t stream);
 
 /* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel carries the two hipEvent_t
  * handles (hipExtLaunchKernelGGL: start / stop of that dispatch on its own stream); the hook disarms after one use. */

@@ -66,17 +66,17 @@ struct Gru16Args {
 // load -> one 16-byte LDS store; all loads of a batch are issued before the first store
 template <int NB>
 __device__ __forceinline__ void stage_frag(float *dst, const float *__restrict__ src, int G, int K, int g_valid) {
-  const int k4 = K >> 2, n4 = G * k4, kb = K >> 4;
-  for (int e0 = threadIdx.x; e0 < n4; e0 += NB * G16_THREADS) {
+  const int k4 = K >> 2, n4 = G * k4, kb = K >> 4, nthr = blockDim.x;
+  for (int e0 = threadIdx.x; e0 < n4; e0 += NB * nthr) {
     float4 v[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int e = min(e0 + j * G16_THREADS, n4 - 1), g = e / k4;
+      const int e = min(e0 + j * nthr, n4 - 1), g = e / k4;
       v[j] = reinterpret_cast<const float4 *>(src)[min(g, g_valid - 1) * k4 + (e - g * k4)];
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int e = e0 + j * G16_THREADS;
+      const int e = e0 + j * nthr;
       if (e < n4) {
         const int g = e / k4, kq = e - g * k4;
         const float4 t = g < g_valid ? v[j] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -88,14 +88,14 @@ __device__ __forceinline__ void stage_frag(float *dst, const float *__restrict__
 // transposed copy: dst block (bo, b) <- M[16 b + 4 q + i][16 bo + n]  (out block over K, k-steps over G)
 template <int NB>
 __device__ __forceinline__ void stage_frag_T(float *dst, const float *__restrict__ src, int G, int K) {
-  const int k4 = K >> 2, n4 = G * k4, gb = G >> 4;
-  for (int e0 = threadIdx.x; e0 < n4; e0 += NB * G16_THREADS) {
+  const int k4 = K >> 2, n4 = G * k4, gb = G >> 4, nthr = blockDim.x;
+  for (int e0 = threadIdx.x; e0 < n4; e0 += NB * nthr) {
     float4 v[NB];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) v[j] = reinterpret_cast<const float4 *>(src)[min(e0 + j * G16_THREADS, n4 - 1)];
+    for (int j = 0; j < NB; ++j) v[j] = reinterpret_cast<const float4 *>(src)[min(e0 + j * nthr, n4 - 1)];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int e = e0 + j * G16_THREADS;
+      const int e = e0 + j * nthr;
       if (e < n4) {
         const int g = e / k4, kq = e - g * k4;
         const float vv[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
@@ -195,7 +195,8 @@ struct F16Lds {
   static constexpr int BH = WH + (HEAD == 1 ? NBH * 4 * 256 : HID);
   static constexpr int TILES = BH + 32;
   static constexpr int UY = 0, UDL = UY + 16 * RS16, WAVE_STRIDE = UDL + (HEAD == 1 ? 16 * DLS : 0);
-  static constexpr int TOTAL = TILES + G16_WAVES * WAVE_STRIDE;
+  static constexpr int TOTAL = TILES + G16_WAVES * WAVE_STRIDE;   // at the full 8 waves; a launch with nw waves asks for total(nw)
+  __host__ __device__ static constexpr int total(int nw) { return TILES + nw * WAVE_STRIDE; }
   static_assert(TOTAL * 4 <= 159 * 1024, "gru16 forward: LDS");
   static_assert(G16_WAVES * NBH * 4 * 256 <= 2 * G16_NG * HID, "epilogue overlays the GRU weights");
 };
@@ -209,28 +210,28 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int nw = blockDim.x / WAVE;                               // 1..8 waves: launches with few tiles spread them over more CUs
   const int A = p.A;
   // ---- staging ----
   stage_frag<6>(lds + M::WIH, p.params + o.gru_wih, G16_NG, HID, G16_NG);
   stage_frag<6>(lds + M::WHH, p.params + o.gru_whh, G16_NG, HID, G16_NG);
-  {
-    const int tid = threadIdx.x;
-    if (tid < 4 * HID) {
-      const int gate = tid >> 6, f = tid & 63;
+  for (int e = threadIdx.x; e < 6 * HID + 32; e += blockDim.x) {
+    if (e < 4 * HID) {
+      const int gate = e >> 6, f = e & 63;
       float v;
-      if (gate < 2) v = p.params[o.gru_bih + tid] + p.params[o.gru_bhh + tid];
+      if (gate < 2) v = p.params[o.gru_bih + e] + p.params[o.gru_bhh + e];
       else if (gate == 2) v = p.params[o.gru_bih + 2 * HID + f];
       else v = p.params[o.gru_bhh + 2 * HID + f];
-      lds[M::BIAS + tid] = v;
-    } else if (tid < 5 * HID) lds[M::RN_G + (tid - 4 * HID)] = p.params[o.rn_w + (tid - 4 * HID)];
-    else if (tid < 6 * HID) lds[M::RN_B + (tid - 5 * HID)] = p.params[o.rn_b + (tid - 5 * HID)];
-    else if (tid < 6 * HID + 32) {
-      const int a = tid - 6 * HID;
+      lds[M::BIAS + e] = v;
+    } else if (e < 5 * HID) lds[M::RN_G + (e - 4 * HID)] = p.params[o.rn_w + (e - 4 * HID)];
+    else if (e < 6 * HID) lds[M::RN_B + (e - 5 * HID)] = p.params[o.rn_b + (e - 5 * HID)];
+    else {
+      const int a = e - 6 * HID;
       lds[M::BH + a] = a < A ? p.params[o.bh + a] : 0.f;
     }
-    if constexpr (HEAD == 1) stage_frag<2>(lds + M::WH, p.params + o.wh, 16 * NBH, HID, A);
-    else if (tid < HID) lds[M::WH + tid] = p.params[o.wh + tid];
   }
+  if constexpr (HEAD == 1) stage_frag<2>(lds + M::WH, p.params + o.wh, 16 * NBH, HID, A);
+  else { if (threadIdx.x < HID) lds[M::WH + threadIdx.x] = p.params[o.wh + threadIdx.x]; }
   __syncthreads();
   float *Uy = lds + M::TILES + wave * M::WAVE_STRIDE + M::UY;
   float *Udl = lds + M::TILES + wave * M::WAVE_STRIDE + M::UDL;
@@ -252,7 +253,7 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
   const int n_ct = (p.Nc + 15) >> 4;
   const int64_t B = (int64_t)p.L * p.Nc;
   const int64_t CS = (int64_t)p.L * n_ct * 1024;                  // floats per scratch component
-  for (int tile = bid * G16_WAVES + wave; tile < n_ct; tile += nb * G16_WAVES) {
+  for (int tile = bid * nw + wave; tile < n_ct; tile += nb * nw) {
     const int c = tile * 16 + n;
     const bool ok = c < p.Nc;
     const int cc = ok ? c : 0;
@@ -439,6 +440,7 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
   __syncthreads();                                               // every wave is done with the weights: their area is free
   float *red = lds;                                              // [wave][NBH * 4][256] head products | vectors behind them
   float *vec = lds + G16_WAVES * NBH * 4 * 256;                  // [wave][8][64]: gNw, gNb, gWc | gBh[bo] (actor: lane n = action 16 bo + n), loss sums
+  const int nthr = blockDim.x;
   if constexpr (HEAD == 1) {
 #pragma unroll
     for (int bo = 0; bo < NBH; ++bo)
@@ -462,20 +464,18 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
   __syncthreads();
   float *slab = p.slabs + (size_t)bid * p.slab_stride + p.slab_col0;
   if constexpr (HEAD == 1) {
-    for (int e = threadIdx.x; e < NBH * 4 * 256; e += G16_THREADS) {
+    for (int e = threadIdx.x; e < NBH * 4 * 256; e += nthr) {
       float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < G16_WAVES; ++w) s += red[w * NBH * 4 * 256 + e];
+      for (int w = 0; w < nw; ++w) s += red[w * NBH * 4 * 256 + e];
       const int blk = e >> 8, ln = (e >> 2) & 63, i = e & 3;
       const int a = 16 * (blk >> 2) + 4 * (ln >> 4) + i, k = 16 * (blk & 3) + (ln & 15);
       if (a < A) slab[o.wh + a * HID + k] = s;
     }
   }
-  if (threadIdx.x < 4 * 64) {
-    const int which = threadIdx.x >> 6, k = threadIdx.x & 63;    // 0: rn_w, 1: rn_b, 2: head vector 0, 3: head vector 1
+  for (int e = threadIdx.x; e < 4 * 64; e += nthr) {
+    const int which = e >> 6, k = e & 63;                        // 0: rn_w, 1: rn_b, 2: head vector 0, 3: head vector 1
     float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < G16_WAVES; ++w) s += vec[(w * 8 + which) * 64 + k];
+    for (int w = 0; w < nw; ++w) s += vec[(w * 8 + which) * 64 + k];
     if (which == 0) slab[o.rn_w + k] = s;
     else if (which == 1) slab[o.rn_b + k] = s;
     else if (HEAD == 1) {
@@ -488,7 +488,7 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double v = 0.0;
-      if (k < 3) for (int w = 0; w < G16_WAVES; ++w) v += (double)vec[(w * 8 + 4) * 64 + k];
+      if (k < 3) for (int w = 0; w < nw; ++w) v += (double)vec[(w * 8 + 4) * 64 + k];
       p.partials[(size_t)bid * 4 + k] = v;
     }
   }
@@ -512,10 +512,11 @@ __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, c
   stage_frag_T<6>(WHT, p.params + o.gru_whh, G16_NG, HID);
   stage_frag_T<6>(WIT, p.params + o.gru_wih, G16_NG, HID);
   __syncthreads();
+  const int nw = blockDim.x / WAVE;
   const int n_ct = (p.Nc + 15) >> 4;
   const int64_t B = (int64_t)p.L * p.Nc;
   const int64_t CS = (int64_t)p.L * n_ct * 1024;
-  for (int tile = bid * G16_WAVES + wave; tile < n_ct; tile += nb * G16_WAVES) {
+  for (int tile = bid * nw + wave; tile < n_ct; tile += nb * nw) {
     const int c = tile * 16 + n;
     const bool ok = c < p.Nc;
     const int cc = ok ? c : 0;
@@ -719,8 +720,19 @@ static int check_rec16(const mappo_net_desc *d, const char *who) {
   MAPPO_REQUIRE(d->out_dim >= 1 && d->out_dim <= MAPPO_MAX_ACTIONS, "%s: out_dim %d", who, d->out_dim);
   return MAPPO_OK;
 }
+// Waves per workgroup of the sequence kernels.  Every workgroup stages its own ~100 KB of weights, and only one fits a CU, so few
+// fat workgroups amortise the staging while thin ones spread a small tile count over more CUs.  Measured (train() of configs
+// 2-rmappo / 3 / 4, ms; scripts/phase_split.py with MAPPO_GRU16_WAVES): 8 waves 5.86 / 23.0 / 12.9, 4 waves 4.95 / 24.9 / 12.8,
+// 2 waves 6.47 / 32.8 / 15.5, 1 wave 9.6 / 50.9 / 21.1 — so: 4 waves up to 256 x 4 tiles, growing to 8 with the tile count.
+static int seq_waves(int Nc) {
+  const int n_ct = (Nc + 15) / 16;
+  int w = (n_ct + NUM_CU - 1) / NUM_CU;
+  w = w < 4 ? (n_ct < 4 ? n_ct : 4) : w;
+  if (const char *e = getenv("MAPPO_GRU16_WAVES")) w = atoi(e);      // diagnostic override (scripts/phase_split.py A/B)
+  return w < 1 ? 1 : (w > G16_WAVES ? G16_WAVES : w);
+}
 static int seq_grid(int Nc) {
-  const int n_ct = (Nc + 15) / 16, want = (n_ct + G16_WAVES - 1) / G16_WAVES;
+  const int n_ct = (Nc + 15) / 16, nw = seq_waves(Nc), want = (n_ct + nw - 1) / nw;
   return want < NUM_CU ? want : NUM_CU;
 }
 static int wg_grid(int L, int Nc) {
@@ -740,7 +752,8 @@ static int fwd16_launch(const Gru16Args &a, dim3 grid, hipStream_t st) {
   typedef F16Lds<HEAD, NBH> M;
   static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_fwd_kernel<HEAD, NBH, XBLK>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
   if (e_ != hipSuccess) { mappo_set_error("gru16_forward_loss: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-  hipLaunchKernelGGL((gru16_fwd_kernel<HEAD, NBH, XBLK>), grid, dim3(G16_THREADS), (size_t)M::TOTAL * sizeof(float), st, a);
+  const int nw = seq_waves(a.Nc);
+  hipLaunchKernelGGL((gru16_fwd_kernel<HEAD, NBH, XBLK>), grid, dim3(WAVE * nw), (size_t)M::total(nw) * sizeof(float), st, a);
   return MAPPO_OK;
 }
 
@@ -786,11 +799,11 @@ extern "C" int mappo_gru16_backward(const float *params, const mappo_net_desc *d
   if (dxT) {
     static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e_ != hipSuccess) { mappo_set_error("gru16_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    hipLaunchKernelGGL(gru16_bwd_kernel<false>, grid, dim3(G16_THREADS), lds_bytes, as_stream(stream), a);
+    hipLaunchKernelGGL(gru16_bwd_kernel<false>, grid, dim3(WAVE * seq_waves(Nc)), lds_bytes, as_stream(stream), a);
   } else {
     static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     if (e_ != hipSuccess) { mappo_set_error("gru16_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    hipLaunchKernelGGL(gru16_bwd_kernel<true>, grid, dim3(G16_THREADS), lds_bytes, as_stream(stream), a);
+    hipLaunchKernelGGL(gru16_bwd_kernel<true>, grid, dim3(WAVE * seq_waves(Nc)), lds_bytes, as_stream(stream), a);
   }
   MAPPO_CHECK_LAUNCH("gru16_backward");
   return MAPPO_OK;

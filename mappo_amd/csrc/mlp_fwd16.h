@@ -161,15 +161,40 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
       for (int r = 0; r < 4; ++r) { const int ar = 16 * bo + 4 * q + r; const float bvv = P[o.bh + min(ar, A - 1)]; bhv[bo][r] = ar < A ? bvv : 0.f; }
     }
   }
-  for (; tile < n_tiles; tile += (int64_t)nb * n_waves) {
-    int64_t i = tile * 16 + j;
-    bool ok = i < p.B;
-    if constexpr (MODE == 3) {                                    // (t, 16 sequences) tiles; every lane computes a real row
-      const int64_t t = tile / n_ct;
-      const int c = (int)(tile - t * n_ct) * 16 + j;
-      i = t * seq_nc + (c < seq_nc ? c : 0);
-      ok = true;
+  if constexpr (MODE == 3) {
+    // Training-sized batches (a wave walks many tiles): the NEXT tile's rows are fetched before this tile's trunk runs, so the
+    // gather latency (row index -> 16 clamped dword loads) hides under ~100 MFMAs instead of preceding them.  (t, 16 sequences)
+    // tiles; every lane computes a real row (lanes beyond seq_nc: sequence 0 of the step).
+    const int64_t stride = (int64_t)nb * n_waves;
+    auto fetch = [&](int64_t tl, f32x4 (&xv)[4]) {
+      const int64_t t = tl / n_ct;
+      const int c = (int)(tl - t * n_ct) * 16 + j;
+      const int64_t i = t * seq_nc + (c < seq_nc ? c : 0);
+      const int64_t row = p.rows ? (int64_t)p.rows[i] : i;
+      const float *src = p.x + row * D;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xv[b][r] = src[min(16 * b + 4 * q + r, D - 1)];
+    };
+    f32x4 xn[4];
+    fetch(tile, xn);
+    for (; tile < n_tiles; tile += stride) {
+      f32x4 x[4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) x[b] = xn[b];
+      fetch(min(tile + stride, n_tiles - 1), xn);
+      f32x4 h[4];
+      trunk16r_apply<RELU, LN>(tw, x, h, D, true, fnorm, q);
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+        *reinterpret_cast<float4 *>(p.out + (tile * 4 + b) * 256 + lane * 4) = make_float4(h[b][0], h[b][1], h[b][2], h[b][3]);
     }
+    return;
+  }
+  for (; tile < n_tiles; tile += (int64_t)nb * n_waves) {
+    const int64_t i = tile * 16 + j;
+    const bool ok = i < p.B;
     const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
     const int64_t off = p.x_M ? (row / p.x_M) * p.x_sn + (row % p.x_M) * p.x_sm : row * D;
     f32x4 x[4];
@@ -180,11 +205,7 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
     f32x4 h[4];
     trunk16r_apply<RELU, LN>(tw, x, h, D, ok, fnorm, q);
     // ---- head ----
-    if constexpr (MODE == 3) {
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        *reinterpret_cast<float4 *>(p.out + (tile * 4 + b) * 256 + lane * 4) = make_float4(h[b][0], h[b][1], h[b][2], h[b][3]);
-    } else if constexpr (MODE == 2) {
+    if constexpr (MODE == 2) {
       if (ok) {
 #pragma unroll
         for (int b = 0; b < 4; ++b)

@@ -88,7 +88,7 @@ class SyntheticSMACEnv:
             self._f = dict(obs=torch.empty(N, M, self.D, device=dev), share=torch.empty(N, M, self.S, device=dev),
                            avail=torch.empty(N, M, self.A, device=dev), rew=torch.empty(N, device=dev),
                            dones=torch.zeros(N, M, dtype=torch.bool, device=dev), bad=torch.zeros(N, M, dtype=torch.bool, device=dev),
-                           ctr=torch.zeros(1, dtype=torch.int64, device=dev))
+                           ctr=torch.tensor([1, 0], dtype=torch.int64, device=dev))       # {Philox counter, tickets}: the kernel advances it
         return self._f
 
     def step(self, actions=None):
@@ -96,7 +96,6 @@ class SyntheticSMACEnv:
         if dev.type == "cuda":
             from mappo_amd import ops
             f = self._fused_state()
-            f["ctr"] += 1
             ops.synth_smac_step(f["obs"], f["share"], f["avail"], f["rew"], self.dead, f["dones"], self.p_death, self.p_term,
                                 self.seed, f["ctr"])
             return f["obs"], f["share"], f["rew"].view(N, 1, 1).expand(N, M, 1), f["dones"], f["bad"], f["avail"]
