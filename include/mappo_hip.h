@@ -302,8 +302,10 @@ int mappo_gru_step_dual(const float *actor_params, const mappo_net_desc *actor_d
                         float *critic_h_last, const float *masks /*[Nc]*/, int32_t Nc, const float *avail /*[Nc][A] or NULL*/,
                         int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
                         float *logp, float *values, mappo_stream_t stream);
-/* The same step with the trunks included (in_dim <= 64, layer_N <= 1): obs / share_obs rows [Nc][in_dim] instead of precomputed
- * features — mappo_mlp_features_dual + mappo_gru_step_dual in ONE launch (r_actor_critic.py:43-70,146-165 end to end). */
+/* The same step with the trunks included: obs / share_obs rows [Nc][in_dim] instead of precomputed features —
+ * mappo_mlp_features_dual + mappo_gru_step_dual in ONE launch (r_actor_critic.py:43-70,146-165 end to end).  Both networks narrow
+ * (in_dim <= 64, layer_N <= 1: every wave runs the tile's trunk from registers) or both wide (65..512, up to 16 384 rows: the
+ * workgroup that ran a tile's split-K trunk goes straight on to its GRU step, the GRU operands fetched under the trunk). */
 int mappo_recurrent_step_dual(const float *actor_params, const mappo_net_desc *actor_desc, const float *obs,
                               const float *actor_h0, float *actor_h_last, const float *critic_params,
                               const mappo_net_desc *critic_desc, const float *share_obs, const float *critic_h0,
@@ -402,11 +404,11 @@ int mappo_mpe_spread_step(double *agent_pos, double *agent_vel, double *landmark
 /* ---- benchmark utility: the synthetic SMAC-shaped vec-env of bench.py / scripts (mappo_amd/envs/synthetic.py), one launch per
  * step.  Not a reference interface (the reference's envs are CPU processes, onpolicy/envs/starcraft2/StarCraft2_Env.py): it only
  * produces data of the SMAC shapes with agents that die and episodes that end.  obs [N][M][D], share_obs [N][M][S] ~ N(0,1);
- * avail [N][M][A] in {0,1}; rewards [N]; dead (state) / dones [N][M] bool bytes; counter_dev [2] = {counter, tickets}:
+ * avail [N][M][A] in {0,1}; rewards [N]; dead (state) / dones [N][M] bool bytes; counter_dev [34] = {counter, 33 tickets}:
  * counter keys the Philox stream and is advanced by the launch itself (last workgroup to finish), tickets must start at 0. */
 int mappo_synth_smac_step(float *obs, float *share_obs, float *avail, float *rewards, uint8_t *dead, uint8_t *dones,
                           int32_t N, int32_t M, int32_t D, int32_t S, int32_t A, float p_death, float p_term,
-                          uint64_t seed, uint64_t *counter_dev /*[2]*/, mappo_stream_t stream);
+                          uint64_t seed, uint64_t *counter_dev /*[34]*/, mappo_stream_t stream);
 
 /* ---- measurement hook (bench.py): the NEXT launch of the entry point's dominant kernel carries the two hipEvent_t
  * handles (hipExtLaunchKernelGGL: start / stop of that dispatch on its own stream); the hook disarms after one use. */

@@ -709,6 +709,139 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gru16_wgrad_kernel(Gru16WgArgs
 }
 
 // ================================================================================================================================
+// trunk features of the sequence-tiled minibatch (in_dim <= 64, layer_N <= 1), blocked output: mlp.py:18-55 up to the trunk's last
+// LayerNorm.  The rollout-sized features kernel (mlp_fwd16.h, weights in REGISTERS: 256 of them, one wave per SIMD) walks ~10
+// tiles per wave at training sizes, each paying its gather and its dependent chain alone: 183 us at BASELINE configs[2].  Here the
+// weights sit in LDS in fragment order (shared by 8 waves, 2 per SIMD) and the next tile's rows are fetched under the current
+// tile's products.
+// ================================================================================================================================
+struct Feat16Args {
+  const float *params;
+  NetOff off;
+  const float *x;
+  const int32_t *rows;
+  int L, Nc, D, fnorm;
+  float *out;                 // blocked [L][n_ct][4][256]
+};
+template <int LN>
+struct T16Lds {
+  static constexpr int W1 = 0, W2 = W1 + HID * HID, B1 = W2 + (LN > 0 ? HID * HID : 0), B2 = B1 + HID;
+  static constexpr int FN_G = B2 + HID, FN_B = FN_G + HID, G1 = FN_B + HID, T1 = G1 + HID, G2 = T1 + HID, T2 = G2 + HID, TOTAL = T2 + HID;
+};
+
+template <bool RELU, int LN>
+__global__ __launch_bounds__(G16_THREADS, 2) void gru16_features_kernel(Feat16Args p) {
+  extern __shared__ __align__(16) float lds[];
+  typedef T16Lds<LN> M;
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), nw = blockDim.x / WAVE;
+  const int D = p.D, kb1 = (D + 15) >> 4;
+  // ---- staging: W1 [64][D] -> fragment blocks (bo, b < kb1), columns >= D zero; W2; vectors (feature-norm vectors zero beyond D) ----
+  for (int e = threadIdx.x; e < HID * kb1 * 4; e += blockDim.x) {
+    const int f = e / (kb1 * 4), kq = e - f * (kb1 * 4);
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int k = 4 * kq + i; const float w = p.params[o.w1 + f * D + min(k, D - 1)]; v[i] = k < D ? w : 0.f; }
+    *reinterpret_cast<float4 *>(lds + M::W1 + (((f >> 4) * kb1 + (kq >> 2)) * 64 + (kq & 3) * 16 + (f & 15)) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if constexpr (LN > 0) stage_frag<2>(lds + M::W2, p.params + o.w2[0], HID, HID, HID);
+  for (int e = threadIdx.x; e < 8 * HID; e += blockDim.x) {
+    const int which = e >> 6, k = e & 63;
+    float v = 0.f;
+    if (which == 0) v = p.params[o.b1 + k];
+    else if (which == 1) { if (LN > 0) v = p.params[o.b2[0] + k]; }
+    else if (which == 2) { if (p.fnorm && k < D) v = p.params[o.fn_w + k]; }
+    else if (which == 3) { if (p.fnorm && k < D) v = p.params[o.fn_b + k]; }
+    else if (which == 4) v = p.params[o.ln1_w + k];
+    else if (which == 5) v = p.params[o.ln1_b + k];
+    else if (which == 6) { if (LN > 0) v = p.params[o.ln2_w[0] + k]; }
+    else { if (LN > 0) v = p.params[o.ln2_b[0] + k]; }
+    lds[M::B1 + e] = v;                                          // B1, B2, FN_G, FN_B, G1, T1, G2, T2 are consecutive
+  }
+  __syncthreads();
+  const int n_ct = (p.Nc + 15) >> 4;
+  const int64_t n_tiles = (int64_t)p.L * n_ct, stride = (int64_t)gridDim.x * nw;
+  const float inv_D = 1.0f / (float)D;
+  int n_pad = 0;                                                  // slots of this lane beyond D (they hold 0)
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n_pad += (16 * b + 4 * q + i >= D) ? 1 : 0;
+  auto fetch = [&](int64_t tl, f32x4 (&xv)[4]) {
+    const int64_t t = tl / n_ct;
+    const int c = (int)(tl - t * n_ct) * 16 + n;
+    const int64_t i = t * p.Nc + (c < p.Nc ? c : 0);
+    const int64_t row = p.rows ? (int64_t)p.rows[i] : i;
+    const float *src = p.x + row * D;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[b][r] = src[min(16 * b + 4 * q + r, D - 1)];
+  };
+  int64_t tile = (int64_t)blockIdx.x * nw + wave;
+  if (tile >= n_tiles) return;
+  f32x4 xn[4];
+  fetch(tile, xn);
+  for (; tile < n_tiles; tile += stride) {
+    f32x4 x[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) x[b][i] = (16 * b + 4 * q + i < D) ? xn[b][i] : 0.f;
+    fetch(min(tile + stride, n_tiles - 1), xn);
+    if (p.fnorm) {
+      float s = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) s += (x[b][0] + x[b][1]) + (x[b][2] + x[b][3]);
+      const float mean = quad_sum16(s) * inv_D;
+      float v = 0.f;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float cdev = x[b][i] - mean; x[b][i] = cdev; v += cdev * cdev; }
+      v -= (float)n_pad * mean * mean;                            // the padded slots contributed (0 - mean)^2 each
+      const float rstd = 1.0f / sqrtf(fmaxf(quad_sum16(v), 0.f) * inv_D + LN_EPS);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const f32x4 g = ld4(lds + M::FN_G + 16 * b + 4 * q), t = ld4(lds + M::FN_B + 16 * b + 4 * q);
+        x[b] = x[b] * f32x4{rstd, rstd, rstd, rstd} * g + t;     // gamma = beta = 0 beyond D: padded slots are exactly 0
+      }
+    }
+    f32x4 h[4];
+#pragma unroll
+    for (int bo = 0; bo < 4; ++bo) h[bo] = ld4(lds + M::B1 + 16 * bo + 4 * q);
+    {
+      const float *base = lds + M::W1 + lane * 4;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        if (b < kb1) {
+          f32x4 a[4];
+#pragma unroll
+          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(base + (bo * kb1 + b) * 256);
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) h[bo] = mfma16(a[bo][i], x[b][i], h[bo]);
+        }
+      }
+    }
+    act_ln16<RELU>(h, lds + M::G1, lds + M::T1, q);
+    if constexpr (LN > 0) {
+      f32x4 h2[4];
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) h2[bo] = ld4(lds + M::B2 + 16 * bo + 4 * q);
+      frag_mma4<4>(h2, lds + M::W2, 0, h, lane);
+      act_ln16<RELU>(h2, lds + M::G2, lds + M::T2, q);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) h[b] = h2[b];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) st4(p.out + (tile * 4 + b) * 256 + lane * 4, h[b]);
+  }
+}
+
+// ================================================================================================================================
 // host
 // ================================================================================================================================
 #ifndef NUM_CU
@@ -745,6 +878,34 @@ extern "C" int64_t mappo_gru16_blocked_floats(int32_t L, int32_t Nc) { return (i
 extern "C" int32_t mappo_gru16_slabs(int32_t L, int32_t Nc) {
   const int a = seq_grid(Nc), b = wg_grid(L, Nc);
   return a > b ? a : b;
+}
+
+template <bool RELU, int LN>
+static int feat16_launch(const Feat16Args &a, dim3 grid, dim3 block, hipStream_t st) {
+  hipLaunchKernelGGL((gru16_features_kernel<RELU, LN>), grid, block, (size_t)T16Lds<LN>::TOTAL * sizeof(float), st, a);
+  return MAPPO_OK;
+}
+
+extern "C" int mappo_mlp_features_seq(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
+                                      int32_t L, int32_t Nc, float *out_blocked, mappo_stream_t stream) {
+  MAPPO_REQUIRE(desc && desc->hidden == HID, "mlp_features_seq: hidden_size unsupported");
+  MAPPO_REQUIRE(params && x && out_blocked && L > 0 && Nc > 0, "mlp_features_seq: bad arguments");
+  MAPPO_REQUIRE(desc->in_dim >= 1 && desc->in_dim <= MAXD && desc->layer_N >= 0 && desc->layer_N <= 1,
+                "mlp_features_seq: in_dim %d / layer_N %d take mappo_mlp_features (feature-major)", desc->in_dim, desc->layer_N);
+  MAPPO_CLEAR_STICKY();
+  Feat16Args a = {};
+  a.params = params; a.off = net_offsets(*desc); a.x = x; a.rows = rows; a.L = L; a.Nc = Nc; a.D = desc->in_dim;
+  a.fnorm = desc->use_feature_norm; a.out = out_blocked;
+  const int64_t n_tiles = (int64_t)L * ((Nc + 15) / 16);
+  const int nw = n_tiles >= 8 * NUM_CU ? 8 : (n_tiles >= 4 * NUM_CU ? 4 : (n_tiles >= 4 ? 4 : 1));
+  int64_t nb = (n_tiles + nw - 1) / nw;
+  if (nb > NUM_CU) nb = NUM_CU;
+  const dim3 grid((unsigned)nb), block(WAVE * nw);
+  const bool relu = desc->use_relu != 0;
+  if (desc->layer_N == 0) { if (relu) feat16_launch<true, 0>(a, grid, block, as_stream(stream)); else feat16_launch<false, 0>(a, grid, block, as_stream(stream)); }
+  else { if (relu) feat16_launch<true, 1>(a, grid, block, as_stream(stream)); else feat16_launch<false, 1>(a, grid, block, as_stream(stream)); }
+  MAPPO_CHECK_LAUNCH("mlp_features_seq");
+  return MAPPO_OK;
 }
 
 template <int HEAD, int NBH, bool XBLK>

@@ -74,7 +74,12 @@ __device__ __forceinline__ void forward16_tail(const FwdArgs &p, float *lds, con
     for (int b = 0; b < 4; ++b) h[b] = h2[b];
   }
   // ---- head ----
-  if (MODE == 2) {
+  if (MODE == 4) {
+    // trunk output handed to the other waves of the workgroup through LDS (wide_recurrent_step_dual_kernel): xs[b][lane]
+    float4 *xs = reinterpret_cast<float4 *>(tZ);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) xs[b * 64 + q * 16 + j] = make_float4(h[b][0], h[b][1], h[b][2], h[b][3]);
+  } else if (MODE == 2) {
     if (ok) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
@@ -135,8 +140,7 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), j = lane & 15, q = lane >> 4;
   const int D = p.desc.in_dim, A = p.desc.out_dim;
-  const int seq_nc = MODE == 3 ? p.seq_nc : 0, n_ct = (seq_nc + 15) >> 4;       // MODE 3: sequence tiling, blocked trunk output
-  const int64_t n_tiles = MODE == 3 ? (p.B / seq_nc) * n_ct : (p.B + 15) / 16;
+  const int64_t n_tiles = (p.B + 15) / 16;
   const bool fnorm = p.desc.use_feature_norm != 0;
   float *tZ = lds + wave * 16 * TP;                              // [16][TP] logits of this wave's samples (MODE 1)
   int64_t tile = (int64_t)bid * n_waves + wave;
@@ -145,7 +149,7 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
   // ---- weights and vectors of this lane (issued before the first wait) ----
   Trunk16R<LN> tw;
   trunk16r_load<LN>(tw, P, o, p.desc, j, q);
-  constexpr int NBH = MODE == 1 ? 2 : (MODE == 0 ? 1 : 0);       // head blocks of 16 outputs (critic: row 0 only; MODE 2 / 3: no head)
+  constexpr int NBH = MODE == 1 ? 2 : (MODE == 0 ? 1 : 0);       // head blocks of 16 outputs (critic: row 0 only)
   f32x4 wh[NBH > 0 ? NBH : 1][4];
   f32x4 bhv[NBH > 0 ? NBH : 1];
   if constexpr (NBH > 0) {
@@ -160,37 +164,6 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
 #pragma unroll
       for (int r = 0; r < 4; ++r) { const int ar = 16 * bo + 4 * q + r; const float bvv = P[o.bh + min(ar, A - 1)]; bhv[bo][r] = ar < A ? bvv : 0.f; }
     }
-  }
-  if constexpr (MODE == 3) {
-    // Training-sized batches (a wave walks many tiles): the NEXT tile's rows are fetched before this tile's trunk runs, so the
-    // gather latency (row index -> 16 clamped dword loads) hides under ~100 MFMAs instead of preceding them.  (t, 16 sequences)
-    // tiles; every lane computes a real row (lanes beyond seq_nc: sequence 0 of the step).
-    const int64_t stride = (int64_t)nb * n_waves;
-    auto fetch = [&](int64_t tl, f32x4 (&xv)[4]) {
-      const int64_t t = tl / n_ct;
-      const int c = (int)(tl - t * n_ct) * 16 + j;
-      const int64_t i = t * seq_nc + (c < seq_nc ? c : 0);
-      const int64_t row = p.rows ? (int64_t)p.rows[i] : i;
-      const float *src = p.x + row * D;
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xv[b][r] = src[min(16 * b + 4 * q + r, D - 1)];
-    };
-    f32x4 xn[4];
-    fetch(tile, xn);
-    for (; tile < n_tiles; tile += stride) {
-      f32x4 x[4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) x[b] = xn[b];
-      fetch(min(tile + stride, n_tiles - 1), xn);
-      f32x4 h[4];
-      trunk16r_apply<RELU, LN>(tw, x, h, D, true, fnorm, q);
-#pragma unroll
-      for (int b = 0; b < 4; ++b)
-        *reinterpret_cast<float4 *>(p.out + (tile * 4 + b) * 256 + lane * 4) = make_float4(h[b][0], h[b][1], h[b][2], h[b][3]);
-    }
-    return;
   }
   for (; tile < n_tiles; tile += (int64_t)nb * n_waves) {
     const int64_t i = tile * 16 + j;

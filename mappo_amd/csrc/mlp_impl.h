@@ -596,11 +596,6 @@ struct FwdArgs {
   // env's output read in place (fused rollout step); x_M == 0: contiguous rows x[i * in_dim]
   int64_t x_sn, x_sm;
   int x_M;
-  // MODE 3 (features16_seq_kernel) only: seq_nc > 0 = sequence tiling (recurrent training): B = L * seq_nc rows in time-major minibatch order are tiled per
-  // (t, 16 sequences) — tile i = (t = i / n_ct, j = i % n_ct), n_ct = ceil(seq_nc / 16) — and the trunk output is written BLOCKED,
-  // out[(i * 4 + b) * 256 + 4 * lane + r] = feature 16 b + 4 q + r of sequence 16 j + n (gru_train16.hip); lanes beyond seq_nc
-  // hold the features of sequence 0 (finite values that only ever meet zero gradients)
-  int seq_nc;
 };
 
 // XW: 0 = in_dim <= 32, 1 = in_dim <= 64 (rows prefetched into registers), 2 = in_dim > 64 (K-chunked layer 1)
@@ -714,12 +709,6 @@ __global__ __launch_bounds__(256, 1) void features16_kernel(FwdArgs a) {
   extern __shared__ __align__(16) float lds[];
   forward16r_body<RELU, LN, 2>(a, lds, blockIdx.x, gridDim.x);
 }
-// the same for the sequence-tiled minibatch of the recurrent training pass: blocked output (FwdArgs::seq_nc, gru_train16.hip)
-template <bool RELU, int LN>
-__global__ __launch_bounds__(256, 1) void features16_seq_kernel(FwdArgs a) {
-  extern __shared__ __align__(16) float lds[];
-  forward16r_body<RELU, LN, 3>(a, lds, blockIdx.x, gridDim.x);
-}
 template <bool RELU, int LN>
 __global__ __launch_bounds__(256, 1) void features16_dual_kernel(FwdArgs a, FwdArgs c, int nA) {
   extern __shared__ __align__(16) float lds[];
@@ -775,7 +764,7 @@ struct UpdArgs {
   int red_base;              // start of that range (b1 for wide inputs: W1 / feature-norm grads come from wide_l1_bwd_kernel)
   float *wide_ws;            // wide inputs: [64][B] dz1 (feature-major) | mean0[B] | rstd0[B]
   const float *dHT;          // HEAD 3: gradient w.r.t. the trunk output, feature-major [64][B]
-  int seq_nc;                // HEAD 3, in_dim <= 64: > 0 = sequence tiling (see FwdArgs::seq_nc) and dHT is BLOCKED per tile
+  int seq_nc;                // HEAD 3, in_dim <= 64: > 0 = the B rows are a time-major [L][seq_nc] minibatch tiled per (t, 16 sequences) and dHT is BLOCKED per tile (gru_train16.hip)
   // HEAD 0
   const float *dout;
   // HEAD 1 / 2 (buffer-order arrays, indexed by rows)
@@ -1318,6 +1307,16 @@ int wide16_launch_forward_sk(int mode, bool relu, int ln, dim3 grid, size_t lds_
                              const char *who);
 int wide16_launch_features_sk_dual(bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
                                    const Wide16Args &wc, const FwdArgs &c, int nA);
+// trunks + GRU step + heads of both networks in one launch (wide_recurrent_step_dual_kernel); one tile per workgroup
+struct WideStepIO {
+  const float *actor_h0, *critic_h0, *masks, *avail;
+  float *actor_h_last, *critic_h_last, *actions, *logp, *values;
+  int Nc, deterministic;
+  uint64_t seed, counter;
+  const uint64_t *counter_dev;
+};
+int wide16_launch_recurrent_step_dual(bool relu, int ln, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                      const Wide16Args &wc, const FwdArgs &c, int nt16, const WideStepIO &io);
 #define WIDE_SK_MAX_TILES 256          // per network: above, the streamed kernels fill the chip
 
 #ifdef MLP_TU_WIDE
@@ -1330,7 +1329,7 @@ static int wide16_l1_fwd_one(const Wide16Args &w, dim3 grid, size_t lds_bytes, h
 }
 int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
   const int nch = (w.D + 63) / 64;
-  const size_t lds_bytes = sizeof(float) * ((size_t)HID * (64 * nch + 4) + HID);      // W1' whole + folded bias
+  const size_t lds_bytes = sizeof(float) * ((size_t)HID * 64 * nch + HID);            // W1' whole (fragment order) + folded bias
   if (nch <= 2) return wide16_l1_fwd_one<2>(w, grid, lds_bytes, st);
   if (nch <= 4) return wide16_l1_fwd_one<4>(w, grid, lds_bytes, st);
   if (nch <= 6) return wide16_l1_fwd_one<6>(w, grid, lds_bytes, st);
@@ -1425,6 +1424,28 @@ int wide16_launch_features_sk_dual(bool relu, int ln, dim3 grid, size_t lds_byte
   if (ln == 0) return relu ? wide16_features_sk_dual_one<true, 0>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 0>(grid, lds_bytes, st, d);
   if (ln == 1) return relu ? wide16_features_sk_dual_one<true, 1>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 1>(grid, lds_bytes, st, d);
   return relu ? wide16_features_sk_dual_one<true, 2>(grid, lds_bytes, st, d) : wide16_features_sk_dual_one<false, 2>(grid, lds_bytes, st, d);
+}
+template <bool R, int L>
+static int wide16_recurrent_step_one(dim3 grid, size_t lds_bytes, hipStream_t st, const WideRecDualArgs &r) {
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_recurrent_step_dual_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("recurrent_step_dual: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  PROF_LAUNCH(MAPPO_PROF_ACT, (wide_recurrent_step_dual_kernel<R, L>), grid, dim3(256), lds_bytes, st, r);
+  return MAPPO_OK;
+}
+int wide16_launch_recurrent_step_dual(bool relu, int ln, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                      const Wide16Args &wc, const FwdArgs &c, int nt16, const WideStepIO &io) {
+  WideRecDualArgs r = {};
+  r.d.wa = wa; r.d.wc = wc; r.d.a = a; r.d.c = c; r.d.nA = nt16;
+  GruFwdArgs &ga = r.ga, &gc = r.gc;
+  ga.params = a.params; ga.off = a.off; ga.desc = a.desc; ga.h0 = io.actor_h0; ga.masks = io.masks; ga.L = 1; ga.Nc = io.Nc; ga.A = a.desc.out_dim;
+  ga.head_mode = 2; ga.h_last = io.actor_h_last; ga.avail = io.avail; ga.actions = io.actions; ga.logp = io.logp;
+  ga.deterministic = io.deterministic; ga.seed = io.seed; ga.counter = io.counter; ga.counter_dev = io.counter_dev;
+  gc.params = c.params; gc.off = c.off; gc.desc = c.desc; gc.h0 = io.critic_h0; gc.masks = io.masks; gc.L = 1; gc.Nc = io.Nc; gc.A = 1;
+  gc.head_mode = 1; gc.h_last = io.critic_h_last; gc.out = io.values;
+  const dim3 grid((unsigned)(2 * nt16));
+  if (ln == 0) return relu ? wide16_recurrent_step_one<true, 0>(grid, lds_bytes, st, r) : wide16_recurrent_step_one<false, 0>(grid, lds_bytes, st, r);
+  if (ln == 1) return relu ? wide16_recurrent_step_one<true, 1>(grid, lds_bytes, st, r) : wide16_recurrent_step_one<false, 1>(grid, lds_bytes, st, r);
+  return relu ? wide16_recurrent_step_one<true, 2>(grid, lds_bytes, st, r) : wide16_recurrent_step_one<false, 2>(grid, lds_bytes, st, r);
 }
 
 #endif
@@ -1636,12 +1657,6 @@ template <bool R, int L>
 static int features16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const FwdArgs &a) {
   static const hipError_t e_ = hipFuncSetAttribute((const void *)features16_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
   if (e_ != hipSuccess) { mappo_set_error("mlp_features: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-  if (a.seq_nc > 0) {
-    static const hipError_t es_ = hipFuncSetAttribute((const void *)features16_seq_kernel<R, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_DYN_MAX);
-    if (es_ != hipSuccess) { mappo_set_error("mlp_features_seq: hipFuncSetAttribute: %s", hipGetErrorString(es_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    hipLaunchKernelGGL((features16_seq_kernel<R, L>), grid, block, lds_bytes, st, a);
-    return MAPPO_OK;
-  }
   hipLaunchKernelGGL((features16_kernel<R, L>), grid, block, lds_bytes, st, a);
   return MAPPO_OK;
 }
@@ -1649,7 +1664,7 @@ static int features16_launch(dim3 grid, dim3 block, size_t lds_bytes, hipStream_
 int launch_features16(const FwdArgs &a_in, hipStream_t st) {
   MAPPO_CLEAR_STICKY();
   FwdArgs a = a_in;
-  const int64_t n_tiles = a.seq_nc > 0 ? (a.B / a.seq_nc) * ((a.seq_nc + 15) / 16) : (a.B + 15) / 16;
+  const int64_t n_tiles = (a.B + 15) / 16;
   const int nw = fit_waves(a.desc, n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1));
   a.off = net_offsets(a.desc); a.map = lds_map(a.desc, nw);
   const size_t lds_bytes = (size_t)a.map.total * sizeof(float);
@@ -1733,6 +1748,40 @@ extern "C" int mappo_mlp_features_dual(const float *params_a, const mappo_net_de
   }
   if (rc) return rc;
   MAPPO_CHECK_LAUNCH("mlp_features_dual");
+  return MAPPO_OK;
+}
+
+// wide-input branch of mappo_recurrent_step_dual (gru.hip): both trunks (split-K), GRU steps and heads in one launch
+#define WIDE_REC_STEP_MAX_TILES 1024
+int mappo_recurrent_step_dual_wide_(const float *actor_params, const mappo_net_desc *actor_desc, const float *obs, const float *actor_h0,
+                                    float *actor_h_last, const float *critic_params, const mappo_net_desc *critic_desc, const float *share_obs,
+                                    const float *critic_h0, float *critic_h_last, const float *masks, int32_t Nc, const float *avail,
+                                    int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
+                                    float *logp, float *values, mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(actor_desc, "recurrent_step_dual")) return rc;
+  if (int rc = check_desc_trunk(critic_desc, "recurrent_step_dual")) return rc;
+  MAPPO_REQUIRE(actor_desc->in_dim > MAXD && critic_desc->in_dim > MAXD && actor_desc->in_dim <= 512 && critic_desc->in_dim <= 512,
+                "recurrent_step_dual: both networks wide (in_dim %d..512)", MAXD + 1);
+  const int64_t nt16 = ((int64_t)Nc + 15) / 16;
+  MAPPO_REQUIRE(nt16 <= WIDE_REC_STEP_MAX_TILES, "recurrent_step_dual: %d rows exceed the one-launch step (mlp_features_dual + gru_step_dual)", Nc);
+  MAPPO_CLEAR_STICKY();
+  FwdArgs a = {}, c = {};
+  a.params = actor_params; a.x = obs; a.desc = *actor_desc; a.B = Nc; a.off = net_offsets(a.desc); a.map = lds_map(a.desc, 8);
+  c.params = critic_params; c.x = share_obs; c.desc = *critic_desc; c.B = Nc; c.off = net_offsets(c.desc); c.map = lds_map(c.desc, 8);
+  Wide16Args wa, wc;
+  size_t lba, lbc;
+  dim3 ga, gc, ba, bc;
+  bool sa, sc;
+  if (int rcp = wide_forward_prepare(a, wa, lba, ga, ba, sa, "recurrent_step_dual")) return rcp;
+  if (int rcp = wide_forward_prepare(c, wc, lbc, gc, bc, sc, "recurrent_step_dual")) return rcp;
+  WideStepIO io = {};
+  io.actor_h0 = actor_h0; io.critic_h0 = critic_h0; io.masks = masks; io.avail = avail; io.actor_h_last = actor_h_last;
+  io.critic_h_last = critic_h_last; io.actions = actions; io.logp = logp; io.values = values; io.Nc = Nc; io.deterministic = deterministic;
+  io.seed = seed; io.counter = counter; io.counter_dev = counter_dev;
+  if (int rcw = wide16_launch_recurrent_step_dual(actor_desc->use_relu != 0, actor_desc->layer_N, lba > lbc ? lba : lbc, as_stream(stream), wa, a,
+                                                  wc, c, (int)nt16, io))
+    return rcw;
+  MAPPO_CHECK_LAUNCH("recurrent_step_dual");
   return MAPPO_OK;
 }
 
@@ -1883,18 +1932,6 @@ extern "C" int mappo_mlp_features(const float *params, const mappo_net_desc *des
   a.params = params; a.x = x; a.rows = rows; a.out = featT; a.desc = *desc; a.B = B;
   if (desc->in_dim <= MAXD) return launch_features16(a, as_stream(stream));
   return launch_forward<2>(a, as_stream(stream), "mlp_features");
-}
-
-// recurrent training (gru_train16.hip): trunk features of the time-major [L][Nc] minibatch, tiled per (t, 16 sequences) and written
-// blocked per tile — the B operand layout of the GRU kernels, one contiguous KiB per wave store
-extern "C" int mappo_mlp_features_seq(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
-                                      int32_t L, int32_t Nc, float *out_blocked, mappo_stream_t stream) {
-  if (int rc = check_desc_trunk(desc, "mlp_features_seq")) return rc;
-  MAPPO_REQUIRE(params && x && out_blocked && L > 0 && Nc > 0, "mlp_features_seq: bad arguments");
-  MAPPO_REQUIRE(desc->in_dim <= MAXD, "mlp_features_seq: in_dim %d > %d takes mappo_mlp_features (feature-major)", desc->in_dim, MAXD);
-  FwdArgs a = {};
-  a.params = params; a.x = x; a.rows = rows; a.out = out_blocked; a.desc = *desc; a.B = (int64_t)L * Nc; a.seq_nc = Nc;
-  return launch_features16(a, as_stream(stream));
 }
 
 extern "C" int mappo_actor_act(const float *params, const mappo_net_desc *desc, const float *obs, const float *avail,

@@ -39,11 +39,17 @@ __device__ __forceinline__ void static_for16(F &&f) { static_for_impl16(f, std::
 template <int LN, int HEAD, bool WIDE, bool XL1 = false>
 struct L16 {
   // XL1: layer 1 runs in its own kernels (mlp_wide16.h forward, wide_l1_bwd_kernel weight gradient): no W1 copy, no xhat0 tile
-  static constexpr int CP = WIDE ? 16 : 8, RS1 = 4 * CP + 4, NBK = WIDE ? 4 : 2, XST = 16 * NBK + 4;
-  static constexpr int W1 = 0;
-  static constexpr int W2 = W1 + (XL1 ? 0 : HID * RS1);                       // W2' [f][k], row stride RS16 (layer_N == 1): forward A operand
-  static constexpr int W2T = W2 + (LN > 0 ? HID * RS16 : 0);      // W2'^T [k][f]: backward-data A operand (16-byte reads, too)
-  static constexpr int WH = W2T + (LN > 0 ? HID * RS16 : 0);      // actor: Wh' [action][k] (16 rows, stride HS16) | critic: Wh' [k]
+  // The three matrices are staged in FRAGMENT order: the 16 x 16 block (bo, b) is 256 consecutive floats, lane (n, q) owning
+  // M[16 bo + n][4 consecutive k of its k-step group] at float offset 4 * lane, so the A operands of four MFMAs are ONE 16-byte
+  // read at base + 16 * lane bytes and each 16-lane group of the ds_read_b128 touches every bank exactly once.  (Round 2 kept
+  // row-major copies with strides 36 / 68: lanes (11, q) and (12, q - 1) of a group then share a bank quad — one conflict cycle
+  // in five, SQ_LDS_BANK_CONFLICT = 31 % of SQ_LDS_IDX_ACTIVE, profiles/r02/dual_update_sq_pmc.txt.)
+  static constexpr int CP = WIDE ? 16 : 8, NT = CP / 4, NBK = WIDE ? 4 : 2, XST = 16 * NBK + 4;
+  static constexpr int W1 = 0;                                    // W1' block (bo, tc): rows 16 bo + n, columns q CP + 4 tc + i
+  static constexpr int W2 = W1 + (XL1 ? 0 : HID * 4 * CP);        // W2' block (bo, b): rows 16 bo + n, columns 16 b + 4 q + i (forward A operand)
+  static constexpr int W2T = W2 + (LN > 0 ? HID * HID : 0);       // W2'^T, the same with rows = k, columns = f (backward-data A operand)
+  static constexpr int WH = W2T + (LN > 0 ? HID * HID : 0);       // actor: Wh' [action][k] (16 rows, stride HS16) | critic: Wh' [k]
+  __host__ __device__ static constexpr int w1_at(int f, int r) { return ((f >> 4) * NT + ((r % CP) >> 2)) * 256 + ((r / CP) * 16 + (f & 15)) * 4 + (r & 3); }
   static constexpr int B1 = WH + (HEAD == 1 ? 16 * HS16 : HID), B2 = B1 + HID, BH = B2 + HID;      // folded biases
   static constexpr int FN_W = BH + 16, FN_B = FN_W + HID, G1 = FN_B + HID, T1 = G1 + HID, G2 = T1 + HID, T2 = G2 + HID;   // raw affine vectors
   static constexpr int TILES = T2 + HID;
@@ -145,17 +151,20 @@ __device__ __forceinline__ void ln_act_bwd16(f32x4 (&d)[4], const f32x4 (&xh)[4]
   }
 }
 
-// out[bo] += W'[16 bo + n][16 b + 4 q + i] * h[b][i]  (W' row-major [f][k], stride RS16): hidden -> hidden forward, and with
+// out[bo] += W'[16 bo + n][16 b + 4 q + i] * h[b][i]  (W' in fragment order, see L16): hidden -> hidden forward, and with
 // the transposed copy the backward-data product.  One 16-byte operand read feeds four MFMAs.  (fp32 MFMAs execute on the
 // vector ALU — SQ_VALU_MFMA_COEXEC_CYCLES reads 0 for this kernel — and the waves wait on LDS for 2 % of their cycles, so
 // there is nothing to gain from software-pipelining the operand reads; the plain form needs the fewest registers.)
+__host__ __device__ constexpr int frag64_at(int row, int col) {   // element (row, col) of a 64 x 64 matrix in fragment order
+  return ((row >> 4) * 4 + (col >> 4)) * 256 + (((col >> 2) & 3) * 16 + (row & 15)) * 4 + (col & 3);
+}
 __device__ __forceinline__ void hidden_fwd16(f32x4 (&out)[4], const f32x4 (&h)[4], const float *sW, int n, int q) {
-  const float *base = sW + n * RS16 + 4 * q;
+  const float *base = sW + (q * 16 + n) * 4;                     // fragment order: block (bo, b) at (4 bo + b) * 256, lane * 4 inside
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
     f32x4 a[4];
 #pragma unroll
-    for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(base + 16 * bo * RS16 + 16 * b);
+    for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(base + (4 * bo + b) * 256);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -164,7 +173,7 @@ __device__ __forceinline__ void hidden_fwd16(f32x4 (&out)[4], const f32x4 (&h)[4
 }
 
 // out[bo] (input features 16 bo + ..) = sum_f W'[f][16 bo + n] * dz[f], f = 16 b + 4 q + i: backward-data of a hidden layer.
-// sWT = W'^T [k][f] (row stride RS16), so the four k-steps of a block are one 16-byte read, as in the forward.
+// sWT = W'^T in fragment order, so the four k-steps of a block are one 16-byte read, as in the forward.
 __device__ __forceinline__ void hidden_bwd16(f32x4 (&out)[4], const f32x4 (&dz)[4], const float *sWT, int n, int q) {
 #pragma unroll
   for (int bo = 0; bo < 4; ++bo) { out[bo][0] = 0.f; out[bo][1] = 0.f; out[bo][2] = 0.f; out[bo][3] = 0.f; }
@@ -491,7 +500,7 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
         const bool ok = t < C && k < D;                          // padding slots of the staged copy are zero
         const int kc = min(k, 63);
         const float w = ok ? w1r[j] : 0.f;
-        lds[M::W1 + f8 * M::RS1 + r] = w * lds[M::FN_W + kc];
+        lds[M::W1 + M::w1_at(f8, r)] = w * lds[M::FN_W + kc];
         pb1 += w * lds[M::FN_B + kc];
       }
     }
@@ -500,8 +509,8 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       const int k = part + 8 * j;
       if constexpr (LN > 0) {
         const float wsc = w2r[j] * lds[M::G1 + k];
-        lds[M::W2 + f8 * RS16 + k] = wsc;
-        lds[M::W2T + k * RS16 + f8] = wsc;
+        lds[M::W2 + frag64_at(f8, k)] = wsc;
+        lds[M::W2T + frag64_at(k, f8)] = wsc;
         pb2 += w2r[j] * lds[M::T1 + k];
       }
       if constexpr (HEAD == 1) {
@@ -661,7 +670,7 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
       if (4 * tc < C) {
         f32x4 a[4];
 #pragma unroll
-        for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(lds + M::W1 + (16 * bo + n) * M::RS1 + q * M::CP + 4 * tc);
+        for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(lds + M::W1 + ((bo * M::NT + tc) * 64 + lane) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (4 * tc + i < C) {

@@ -273,7 +273,7 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
 }
 
 // wide_l1_fwd16_kernel — training-sized batches: W1' (gamma folded in) is staged ONCE per workgroup into LDS, whole
-// ([64][64 nch + 4] floats: 132 KB at in_dim 512), so the tile loop has no barrier and no weight traffic at all: the 8 waves walk
+// (64 x 64 nch floats in fragment order: 128 KB at in_dim 512), so the tile loop has no barrier and no weight traffic at all: the 8 waves walk
 // their tiles independently (one wave's row loads and statistics run under the other waves' MFMAs).  Streaming the chunks
 // through a double buffer (wide16_layer1, kept for the rollout kernel where a workgroup sees too few tiles to amortise the
 // staging) left every chunk waiting for an L2 round trip behind a workgroup barrier: 4 us per chunk against 2 us of MFMA.
@@ -287,16 +287,21 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   const bool al4 = (D & 3) == 0;
   const float inv_D = 1.0f / (float)D;
   const int c_last = (D + 63) / 64 - 1;
-  const int RSW = 64 * (c_last + 1) + 4;                       // row stride of W1' in LDS (== 4 mod 64: conflict-free 16-byte reads)
-  float *sW = lds, *sB = lds + HID * RSW;
+  // W1' in LDS in FRAGMENT order: the 16 x 16 block (bo, kb) — rows 16 bo + n, columns 16 kb + 4 q + t — is 256 consecutive
+  // floats with lane (n, q)'s four values at float offset 4 * lane, so an A operand read is base + 16 * lane bytes and every
+  // 16-lane group of the ds_read_b128 covers the 64 banks once.  (The row-major copy with stride 64 nch + 4 of round 2 put lanes
+  // (11, q) and (12, q - 1) of a group on one bank quad: SQ_LDS_BANK_CONFLICT was 49 % of SQ_LDS_IDX_ACTIVE — one conflict cycle
+  // per MFMA, profiles/r02/d_wide_l1_kernels_sq_pmc.txt.)
+  const int KB = 4 * (c_last + 1);                              // 16-column blocks per row
+  float *sW = lds, *sB = lds + HID * 16 * KB;
   // ---- stage W1' = W1 gamma0 (zeros beyond the row) and the folded bias ----
   {
-    const int nv = RSW / 4 - 1;                                // 16-byte groups per row
+    const int nv = 4 * KB;                                      // 16-byte groups per row
     for (int e = tid; e < HID * nv; e += blockDim.x) {
-      const int f = e / nv, k = 4 * (e - f * nv);
+      const int f = e / nv, g4 = e - f * nv, k = 4 * g4;
       f32x4 w = ld4_row(p.params + p.w1 + (size_t)f * D, k, D, al4);
       if (fnorm) w *= ld4_row(p.params + p.fn_w, k, D, al4);
-      st4(sW + f * RSW + k, w);
+      st4(sW + (((f >> 4) * KB + (g4 >> 2)) * 64 + (g4 & 3) * 16 + (f & 15)) * 4, w);
     }
     wide16_fold_bias<8>(p, sB);
   }
@@ -385,12 +390,12 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       if (c <= c_last) {
-        const float *Wc = sW + n * RSW + 4 * q + 64 * c;
+        const float *Wc = sW + (4 * c * 64 + lane) * 4;          // block (bo, kb = 4 c + jj) at (bo KB + kb) * 256
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           f32x4 a[4];
 #pragma unroll
-          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + 16 * bo * RSW + 16 * jj);
+          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + (bo * KB + jj) * 256);
 #pragma unroll
           for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -520,7 +525,8 @@ struct SkShared {
 };
 
 template <bool RELU, int LN, int MODE>
-__device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, const FwdArgs &p, float *lds, SkShared &sh, const int bid, const int nb) {
+__device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, const FwdArgs &p, float *lds, SkShared &sh, const int bid, const int nb,
+                                                       float *xshare = nullptr) {      // MODE 4: the trunk output goes to xshare[4][64] float4
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = w.D;
@@ -633,7 +639,7 @@ __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, cons
         }
         acc[bo] += b1;
       }
-      forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, jq, q, tZ);
+      forward16_tail<RELU, LN, MODE>(p, lds, p.map, acc, i, ok, jq, q, MODE == 4 ? xshare : tZ);
     }
     __syncthreads();                                           // sAcc / sS / sV free for the next tile
   }
@@ -653,6 +659,44 @@ __global__ __launch_bounds__(256, 1) void wide_features16_sk_dual_kernel(WideDua
   if ((int)blockIdx.x < d.nA) wide_forward16_sk_body<RELU, LN, 2>(d.wa, d.a, lds, sh, blockIdx.x, d.nA);
   else wide_forward16_sk_body<RELU, LN, 2>(d.wc, d.c, lds, sh, (int)blockIdx.x - d.nA, (int)gridDim.x - d.nA);
 }
+
+#ifdef MLP_TU_WIDE_SK
+// ---- one rollout step of a recurrent actor AND critic with wide inputs in ONE launch (r_actor_critic.py:43-70,146-165;
+// smac_runner.py:110-127) ----
+// Round 2 ran such a step as two launches (mappo_mlp_features_dual: split-K trunks -> featT in HBM; mappo_gru_step_dual: GRU cell +
+// rnn.norm + heads), 21 + 14 us at BASELINE configs[3] where the arithmetic is a few microseconds: two launch latencies, two
+// weight-fetch latencies and a feature round trip through HBM.  Here the 4-wave workgroup that runs a tile's split-K trunk goes
+// straight on to the tile's GRU step: the GRU / head operands of every wave are requested BEFORE the trunk starts (they land
+// under it), wave 0's trunk output crosses to the other waves through 4 KB of LDS, and gru_step3_tiles finishes the row.
+#include "gru_step3.h"
+struct WideRecDualArgs {
+  WideDualArgs d;
+  GruFwdArgs ga, gc;
+};
+template <bool RELU, int LN>
+__global__ __launch_bounds__(256, 1) void wide_recurrent_step_dual_kernel(WideRecDualArgs r) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ SkShared sh;
+  __shared__ Step3Shared s3;
+  __shared__ float4 sX[4 * 64];
+  const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const bool actor = (int)blockIdx.x < r.d.nA;                    // one tile per workgroup: grid = 2 x tiles
+  const int bid = actor ? (int)blockIdx.x : (int)blockIdx.x - r.d.nA, nb = r.d.nA;
+  Step3W<0> W;
+  if (actor) {
+    gru_step3_load<3, 0>(W, r.ga, wv, n, q);
+    wide_forward16_sk_body<RELU, LN, 4>(r.d.wa, r.d.a, lds, sh, bid, nb, reinterpret_cast<float *>(sX));
+    gru_step3_tiles<2, 3, 0>(W, r.ga, s3, bid, nb, sX);
+  } else {
+    gru_step3_load<3, 0>(W, r.gc, wv, n, q);
+    wide_forward16_sk_body<RELU, LN, 4>(r.d.wc, r.d.c, lds, sh, bid, nb, reinterpret_cast<float *>(sX));
+    gru_step3_tiles<1, 3, 0>(W, r.gc, s3, bid, nb, sX);
+  }
+}
+#undef GS
+#undef NG
+#endif
 
 // ------------------------------------------------------------------------------------------------------------------------
 // wide_l1_bwd16_kernel — weight gradient of layer 1 and the feature-norm gradients for in_dim 65..512 from dz1 and the row

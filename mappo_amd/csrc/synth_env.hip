@@ -8,7 +8,7 @@
 //   p_death per step;  an env terminates with probability p_term per step (all agents done, restarts alive);
 //   dones = dead | terminated.
 // Counter-based Philox stream keyed by (seed, counter_dev[0]): a pure device op, capturable into the rollout hipGraph.  The
-// launch advances the counter ITSELF: every workgroup reads it first and takes a ticket (counter_dev[1]) when it is done; the
+// launch advances the counter ITSELF: every workgroup reads it first and takes a ticket (counter_dev[1..33]) when it is done; the
 // workgroup that draws the last ticket stores counter + 1 and clears the tickets — no second launch per step for a `ctr += 1`
 // (that elementwise launch was 4.5 us of every rollout step).
 #include "mlp_core.h"
@@ -16,7 +16,7 @@
 struct SynthArgs {
   float *obs, *share, *avail, *rewards;
   uint8_t *dead, *dones;
-  uint64_t *counter_dev;      // [2]: counter, tickets
+  uint64_t *counter_dev;      // [34]: counter, group-of-groups tickets, 32 group tickets
   int N, M, D, S, A;
   float p_death, p_term;
   uint64_t seed;
@@ -55,12 +55,18 @@ __global__ __launch_bounds__(256) void synth_smac_step_kernel(SynthArgs p) {
     }
   }
   // advance the stream: the last workgroup to finish (every workgroup has read the counter by then)
+  // (two levels, 32 groups: a single ticket counter serialises one atomic per workgroup — 12 us for 4 096 of them)
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned long long t = atomicAdd(reinterpret_cast<unsigned long long *>(p.counter_dev + 1), 1ull);
-    if (t == (unsigned long long)gridDim.x - 1ull) {
-      p.counter_dev[1] = 0ull;
-      p.counter_dev[0] = ctr + 1ull;
+    unsigned long long *tk = reinterpret_cast<unsigned long long *>(p.counter_dev);
+    const unsigned n_groups = gridDim.x < 32u ? gridDim.x : 32u, g = blockIdx.x % n_groups;
+    const unsigned in_group = (gridDim.x - g + n_groups - 1u) / n_groups;       // workgroups b with b % n_groups == g
+    if (atomicAdd(tk + 2 + g, 1ull) == (unsigned long long)in_group - 1ull) {
+      tk[2 + g] = 0ull;
+      if (atomicAdd(tk + 1, 1ull) == (unsigned long long)n_groups - 1ull) {
+        tk[1] = 0ull;
+        tk[0] = ctr + 1ull;
+      }
     }
   }
 }

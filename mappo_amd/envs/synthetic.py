@@ -88,7 +88,7 @@ class SyntheticSMACEnv:
             self._f = dict(obs=torch.empty(N, M, self.D, device=dev), share=torch.empty(N, M, self.S, device=dev),
                            avail=torch.empty(N, M, self.A, device=dev), rew=torch.empty(N, device=dev),
                            dones=torch.zeros(N, M, dtype=torch.bool, device=dev), bad=torch.zeros(N, M, dtype=torch.bool, device=dev),
-                           ctr=torch.tensor([1, 0], dtype=torch.int64, device=dev))       # {Philox counter, tickets}: the kernel advances it
+                           ctr=torch.tensor([1] + [0] * 33, dtype=torch.int64, device=dev))       # {Philox counter, 33 tickets}: the kernel advances it
         return self._f
 
     def step(self, actions=None):

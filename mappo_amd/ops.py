@@ -553,9 +553,9 @@ def mpe_spread_step(agent_pos, agent_vel, landmark_pos, tstep, episode, actions,
 
 
 def synth_smac_step(obs, share_obs, avail, rewards, dead, dones, p_death, p_term, seed, counter):
-    """One step of the synthetic SMAC-shaped env (bench utility, csrc/synth_env.hip); `counter`: int64 [2] device tensor
-    {Philox counter, tickets (0)}: the launch advances the counter itself."""
-    assert counter.numel() == 2
+    """One step of the synthetic SMAC-shaped env (bench utility, csrc/synth_env.hip); `counter`: int64 [34] device tensor
+    {Philox counter, 33 tickets (0)}: the launch advances the counter itself."""
+    assert counter.numel() == 34
     N, M, D = obs.shape
     rc = _lib.load().mappo_synth_smac_step(_ptr(obs), _ptr(share_obs), _ptr(avail), _ptr(rewards), _ptr(dead, torch.bool), _ptr(dones, torch.bool),
                                            int(N), int(M), int(D), int(share_obs.shape[2]), int(avail.shape[2]), float(p_death), float(p_term),

@@ -58,6 +58,7 @@ class _Scratch:
 
 _scratch = _Scratch()
 _USE_GRU16 = os.environ.get("MAPPO_GRU16", "1") != "0"      # diagnostic switch while the round-2 training kernels still exist
+_TWO_STREAMS = os.environ.get("MAPPO_REC_TWO_STREAMS", "1") != "0"   # the two networks' chains on two streams (A/B: one after the other)
 
 
 def _seq_shape(n_rows, rnn_states):
@@ -102,8 +103,10 @@ def step_dual(actor, critic, obs, cent_obs, rnn_a, rnn_c, masks, avail, determin
     dev = actor.device_
     ha = torch.empty(Nc, 1, H, dtype=torch.float32, device=dev)
     hc = torch.empty(Nc, 1, H, dtype=torch.float32, device=dev)
-    if (max(actor.desc.in_dim, critic.desc.in_dim) <= 64 and actor.desc.layer_N <= 1 and Nc <= 1024
+    wide = min(actor.desc.in_dim, critic.desc.in_dim) > 64
+    if (((max(actor.desc.in_dim, critic.desc.in_dim) <= 64 and actor.desc.layer_N <= 1 and Nc <= 1024) or (wide and Nc <= 16 * 1024))
             and os.environ.get("MAPPO_FUSED_STEP", "1") != "0"):
+        # wide inputs: split-K trunks + GRU step + heads of both networks in one launch, one 16-row tile per 4-wave workgroup
         # narrow inputs, at most 64 tiles per network: trunks, GRU steps and heads of both networks in ONE launch (every wave
         # of a tile's workgroup holds the trunk's weights in registers — with more tiles the separate launches, which stage the
         # weights once per workgroup of four tiles, are faster: 3 072 rows measured 2x slower fused)
@@ -225,7 +228,7 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
 
     # The sequential GRU kernels occupy one wave per 32 sequences (240 of the chip's 1024 SIMDs at BASELINE config 2), so
     # the two networks' chains run side by side on two streams; they write disjoint slab columns and disjoint partials.
-    if len(nets) == 2:
+    if len(nets) == 2 and _TWO_STREAMS:
         cur = torch.cuda.current_stream()
         if tr._side_stream is None:
             tr._side_stream = torch.cuda.Stream(device=dev)
@@ -236,7 +239,8 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
         one_net(*nets[1])
         cur.wait_stream(side)
     else:
-        one_net(*nets[0])
+        for nt in nets:
+            one_net(*nt)
     ops.update_stats(pa if update_actor else None, n_bwd, pc, n_bwd, tr._mb_moments, tr._cfg, tr._stats, tr._acc)
     if update_actor != tr._actor_enabled:
         pol.opt_hyper[0, 7] = 1.0 if update_actor else 0.0
