@@ -262,35 +262,18 @@ int mappo_update_stats(const double *actor_partials, int32_t n_actor /*workgroup
                        mappo_stream_t stream);
 
 /* ---- K9: recurrent layer (onpolicy/algorithms/utils/rnn.py:7-80: nn.GRU(64,64) with per-step h*mask + LayerNorm) ----
- * A recurrent network = trunk (mappo_mlp_features) -> GRU -> rnn.norm -> head.  Scratch between the kernels is
- * feature-major: featT / dxT are [64][B], B = L*Nc, column t*Nc + c (time-major over Nc sequences, the order of
- * recurrent_generator's stacked chunks, shared_buffer.py:438-474); `rows` maps column -> flat buffer row.
+ * A recurrent network = trunk (mappo_mlp_features) -> GRU -> rnn.norm -> head.  Outside the training pass (below: the
+ * mappo_gru16_* entry points) features are feature-major: featT is [64][B], B = L*Nc, column t*Nc + c (time-major over Nc
+ * sequences, the order of recurrent_generator's stacked chunks, shared_buffer.py:438-474); `rows` maps column -> flat buffer row.
  *   mappo_mlp_features   trunk forward, LayerNorm output of the last layer, feature-major
  *   mappo_gru_forward    L steps from h0[h0_rows] (row-major [.][64]); head_mode 0: states only, 1: head output
- *                        out[B][A] per step, 2: sample/argmax + log-prob (rollout, L = 1); scratch != NULL stores
- *                        {h*mask, r, z, n, W_hn h + b_hn, h'} per step for the backward pass
- *   mappo_gru_backward   reverse time with the PPO loss of the step computed in the kernel (head 1 actor, 2 critic):
- *                        writes dxT (gradient at the trunk output), dgiT [192][B], dghnT [64][B], loss partials and the
- *                        head + rnn.norm columns of one slab per workgroup
- *   mappo_gru_wgrad      dW_ih, dW_hh, db_ih, db_hh from (dgi, featT) and (dgh, h*mask) -> slabs
+ *                        out[B][A] per step, 2: sample/argmax + log-prob (rollout, L = 1)
  *   mappo_trunk_backward backward of the trunk given dxT (forward recomputed per tile, as mappo_mlp_backward) */
 int mappo_mlp_features(const float *params, const mappo_net_desc *desc /*host*/, const float *x, const int32_t *rows,
                        int64_t B, float *featT /*[64][B]*/, mappo_stream_t stream);
-int64_t mappo_gru_scratch_floats(int32_t L, int32_t Nc);
-/* Input-side products of the GRU, outside the sequential kernels (no time dependence: plain row-tile products over all
- * B = L*Nc rows):  giT [192][B] = W_ih featT + b_ih   and   dxT [64][B] = W_ih^T dgiT.  mappo_gru_forward with giT != NULL
- * then carries only the W_hh half of the matrix work, with two waves per 32 sequences (one per half of the hidden
- * features).  mappo_gru_backward is two launches: the row-local half (rnn.norm, head, PPO loss and their backward) over all
- * B rows at once, which OVERWRITES the h' component of `scratch` with d h', then the recurrence proper (same two-wave
- * form); with dxT != NULL it finishes with mappo_gru_input_backward(dgiT -> dxT). */
-int mappo_gru_input_gates(const float *params, const mappo_net_desc *desc /*host*/, const float *featT /*[64][B]*/, int64_t B,
-                          float *giT /*[192][B]*/, mappo_stream_t stream);
-int mappo_gru_input_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *dgiT /*[192][B]*/, int64_t B,
-                             float *dxT /*[64][B]*/, mappo_stream_t stream);
-int mappo_gru_forward(const float *params, const mappo_net_desc *desc /*host*/, const float *featT,
-                      const float *giT /*[192][B] from mappo_gru_input_gates, or NULL: computed in the kernel*/, const float *h0,
+int mappo_gru_forward(const float *params, const mappo_net_desc *desc /*host*/, const float *featT, const float *h0,
                       const int32_t *h0_rows /*[Nc] or NULL*/, const float *masks, const int32_t *rows /*[B] or NULL*/,
-                      int32_t L, int32_t Nc, float *h_last /*[Nc][64] or NULL*/, float *scratch /*or NULL*/,
+                      int32_t L, int32_t Nc, float *h_last /*[Nc][64] or NULL*/,
                       int32_t head_mode, float *out, const float *avail /*[B][A] or NULL*/, int32_t deterministic,
                       uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions, float *logp,
                       mappo_stream_t stream);
@@ -316,17 +299,6 @@ int mappo_recurrent_step_dual(const float *actor_params, const mappo_net_desc *a
 int mappo_mlp_features_dual(const float *params_a, const mappo_net_desc *desc_a /*host*/, const float *x_a, float *featT_a,
                             const float *params_c, const mappo_net_desc *desc_c /*host*/, const float *x_c, float *featT_c,
                             int64_t B, mappo_stream_t stream);
-int32_t mappo_gru_backward_slabs(int32_t Nc);
-int mappo_gru_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *scratch, const float *masks,
-                       const int32_t *rows, int32_t L, int32_t Nc, int32_t head, const float *avail, const float *actions,
-                       const float *old_logp, const float *adv, const float *active, const float *v_old,
-                       const float *returns, const float *vn_state, const double *mb_moments,
-                       const mappo_ppo_cfg *cfg /*host*/, float *dxT, float *dgiT, float *dghnT, float *slabs,
-                       int64_t slab_stride, int64_t slab_col0, double *partials, mappo_stream_t stream);
-int32_t mappo_gru_wgrad_slabs(int32_t L, int32_t Nc);
-int mappo_gru_wgrad(const mappo_net_desc *desc /*host*/, const float *featT, const float *scratch, const float *dgiT,
-                    const float *dghnT, int32_t L, int32_t Nc, float *slabs, int64_t slab_stride, int64_t slab_col0,
-                    mappo_stream_t stream);
 int mappo_trunk_backward(const float *params, const mappo_net_desc *desc /*host*/, const float *x, const int32_t *rows,
                          int64_t B, const float *dxT /*[64][B]*/, float *slabs, int64_t slab_stride, int64_t slab_col0,
                          float *wide_ws /*or NULL*/, mappo_stream_t stream);

@@ -69,10 +69,7 @@ SIGNATURES = {
                                             C.POINTER(PpoCfg), _P, _I64, _I64, _I64, _P, _P, _P]),
     "mappo_update_stats": (C.c_int, [_P, _I32, _P, _I32, _P, C.POINTER(PpoCfg), _P, _P, _P]),
     "mappo_mlp_features": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P]),
-    "mappo_gru_scratch_floats": (_I64, [_I32, _I32]),
-    "mappo_gru_input_gates": (C.c_int, [_P, C.POINTER(NetDesc), _P, _I64, _P, _P]),
-    "mappo_gru_input_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _I64, _P, _P]),
-    "mappo_gru_forward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _I32, _P, _P, _I32, _U64, _U64,
+    "mappo_gru_forward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, _P, _P, _I32, _I32, _P, _I32, _P, _P, _I32, _U64, _U64,
                                     _P, _P, _P, _P]),
     "mappo_gru_step_dual": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, _P, C.POINTER(NetDesc), _P, _P, _P, _P, _I32, _P, _I32, _U64, _U64,
                                       _P, _P, _P, _P, _P]),
@@ -88,11 +85,6 @@ SIGNATURES = {
     "mappo_gru16_wgrad": (C.c_int, [C.POINTER(NetDesc), _P, _I32, _P, _I32, _I32, _P, _I64, _I64, _P]),
     "mappo_trunk_backward_seq": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _I64, _I64, _P]),
     "mappo_mlp_features_dual": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, C.POINTER(NetDesc), _P, _P, _I64, _P]),
-    "mappo_gru_backward_slabs": (_I32, [_I32]),
-    "mappo_gru_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, _I32, _I32, _I32] + [_P] * 9 + [C.POINTER(PpoCfg), _P, _P, _P, _P,
-                                     _I64, _I64, _P, _P]),
-    "mappo_gru_wgrad_slabs": (_I32, [_I32, _I32]),
-    "mappo_gru_wgrad": (C.c_int, [C.POINTER(NetDesc), _P, _P, _P, _P, _I32, _I32, _P, _I64, _I64, _P]),
     "mappo_trunk_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _I64, _I64, _P, _P]),
     "mappo_optim_workspace_bytes": (_I64, [_I64]),
     "mappo_slab_reduce": (C.c_int, [_P, _I32, _I64, _I64, _P, _P]),

@@ -299,7 +299,7 @@ class R_MAPPO():
             self._actor_enabled = update_actor
         if not update_actor and not self._actor_slabs_clean:
             for (name, _, _), t in self._ws.items():
-                if name in ("slabs", "slabs_rec", "slabs_rec16"):
+                if name in ("slabs", "slabs_rec"):
                     t[:, :self.policy.seg_bounds[1]].zero_()
         self._actor_slabs_clean = not update_actor
 

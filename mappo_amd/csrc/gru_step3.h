@@ -47,7 +47,6 @@ struct GruFwdArgs {
   NetOff off;
   GruLds map;
   const float *xT;            // [64][B] trunk features, B = L*Nc, column t*Nc + c
-  const float *giT;           // optional [192][B] precomputed input gates (training): the cell then skips the W_ih products
   const float *h0;            // [.][64] row-major initial states
   const int32_t *h0_rows;     // [Nc] or NULL (identity)
   const float *masks;         // buffer-order masks, indexed by rows[t*Nc + c] (NULL rows = identity)
@@ -55,7 +54,6 @@ struct GruFwdArgs {
   int L, Nc, A, head_mode;    // head_mode 0: none, 1: out[B][A], 2: sample (actions/logp [B])
   int tile_waves;             // waves of a workgroup that own tiles; any further waves only help staging the weights
   float *h_last;              // [Nc][64] row-major or NULL
-  float *scratch;             // [6][L][64][Nc] or NULL (training)
   float *out;
   const float *avail;         // [B][A] minibatch order, or NULL
   float *actions, *logp;

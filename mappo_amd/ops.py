@@ -344,28 +344,12 @@ def mlp_features(params, desc, x, rows, B, featT):
     _lib.check(rc, "mappo_mlp_features")
 
 
-def gru_scratch_floats(L, Nc):
-    return int(_lib.load().mappo_gru_scratch_floats(int(L), int(Nc)))
-
-
-def gru_input_gates(params, desc, featT, B, giT):
-    """giT [192][B] = W_ih featT + b_ih for all rows at once (training: outside the sequential kernel)."""
-    rc = _lib.load().mappo_gru_input_gates(_ptr(params), C.byref(desc), _ptr(featT), int(B), _ptr(giT), _stream())
-    _lib.check(rc, "mappo_gru_input_gates")
-
-
-def gru_input_backward(params, desc, dgiT, B, dxT):
-    """dxT [64][B] = W_ih^T dgiT for all rows at once."""
-    rc = _lib.load().mappo_gru_input_backward(_ptr(params), C.byref(desc), _ptr(dgiT), int(B), _ptr(dxT), _stream())
-    _lib.check(rc, "mappo_gru_input_backward")
-
-
-def gru_forward(params, desc, featT, h0, h0_rows, masks, rows, L, Nc, h_last=None, scratch=None, head_mode=0, out=None,
-                avail=None, deterministic=False, seed=0, counter=0, counter_dev=None, actions=None, logp=None, giT=None):
-    rc = _lib.load().mappo_gru_forward(_ptr(params), C.byref(desc), _ptr(featT), _ptr(giT, allow_none=True), _ptr(h0),
+def gru_forward(params, desc, featT, h0, h0_rows, masks, rows, L, Nc, h_last=None, head_mode=0, out=None,
+                avail=None, deterministic=False, seed=0, counter=0, counter_dev=None, actions=None, logp=None):
+    rc = _lib.load().mappo_gru_forward(_ptr(params), C.byref(desc), _ptr(featT), _ptr(h0),
                                        _ptr(h0_rows, torch.int32, allow_none=True),
                                        _ptr(masks), _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc),
-                                       _ptr(h_last, allow_none=True), _ptr(scratch, allow_none=True), int(head_mode),
+                                       _ptr(h_last, allow_none=True), int(head_mode),
                                        _ptr(out, allow_none=True), _ptr(avail, allow_none=True), int(bool(deterministic)),
                                        int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
                                        _ptr(counter_dev, torch.int64, allow_none=True), _ptr(actions, allow_none=True),
@@ -400,31 +384,6 @@ def mlp_features_dual(params_a, desc_a, x_a, featT_a, params_c, desc_c, x_c, fea
     rc = _lib.load().mappo_mlp_features_dual(_ptr(params_a), C.byref(desc_a), _ptr(x_a), _ptr(featT_a), _ptr(params_c), C.byref(desc_c),
                                              _ptr(x_c), _ptr(featT_c), int(B), _stream())
     _lib.check(rc, "mappo_mlp_features_dual")
-
-
-def gru_backward_slabs(Nc):
-    return int(_lib.load().mappo_gru_backward_slabs(int(Nc)))
-
-
-def gru_backward(params, desc, scratch, masks, rows, L, Nc, head, avail, actions, old_logp, adv, active, v_old, returns, vn_state,
-                 mb_moments, cfg, dxT, dgiT, dghnT, slabs, slab_stride, slab_col0, partials):
-    n = lambda t: _ptr(t, allow_none=True)
-    rc = _lib.load().mappo_gru_backward(_ptr(params), C.byref(desc), _ptr(scratch), _ptr(masks), _ptr(rows, torch.int32, allow_none=True),
-                                        int(L), int(Nc), int(head), n(avail), n(actions), n(old_logp), n(adv), _ptr(active), n(v_old),
-                                        n(returns), n(vn_state), _ptr(mb_moments, torch.float64), C.byref(cfg), n(dxT), _ptr(dgiT),
-                                        _ptr(dghnT), _ptr(slabs), int(slab_stride), int(slab_col0), _ptr(partials, torch.float64),
-                                        _stream())
-    _lib.check(rc, "mappo_gru_backward")
-
-
-def gru_wgrad_slabs(L, Nc):
-    return int(_lib.load().mappo_gru_wgrad_slabs(int(L), int(Nc)))
-
-
-def gru_wgrad(desc, featT, scratch, dgiT, dghnT, L, Nc, slabs, slab_stride, slab_col0):
-    rc = _lib.load().mappo_gru_wgrad(C.byref(desc), _ptr(featT), _ptr(scratch), _ptr(dgiT), _ptr(dghnT), int(L), int(Nc), _ptr(slabs),
-                                     int(slab_stride), int(slab_col0), _stream())
-    _lib.check(rc, "mappo_gru_wgrad")
 
 
 def trunk_backward(params, desc, x, rows, B, dxT, slabs, slab_stride, slab_col0):

@@ -1,10 +1,12 @@
 """GRU (recurrent policy) path — `onpolicy/algorithms/utils/rnn.py:7-80`, the chunked / whole-episode generators
 (`shared_buffer.py:288-494`) and the recurrent branch of `R_MAPPO.train` (`r_mappo.py:194-200`).
 
-A recurrent network is trunk -> GRU -> LayerNorm -> head.  Forward: mappo_mlp_features (trunk, feature-major
-[64][B]) + mappo_gru_forward.  Training, per network and minibatch of `mbs` chunks x L steps (time-major, the order
-of the reference's stacked chunks): features -> gru_forward (stores gates) -> gru_backward (reverse time, head +
-in-kernel PPO loss, d x) -> gru_wgrad -> trunk_backward, all writing gradient slabs over the joint flat layout.
+A recurrent network is trunk -> GRU -> LayerNorm -> head.  Forward outside the training pass: mappo_mlp_features (trunk,
+feature-major [64][B]) + mappo_gru_forward, or the one-launch rollout step of both networks (mappo_recurrent_step_dual).
+Training, per network and minibatch of `mbs` chunks x L steps (time-major, the order of the reference's stacked chunks), on
+16-sequence tiles (csrc/gru_train16.hip): trunk features (blocked) -> gru16_forward_loss (input + hidden products, gates, rnn.norm,
+head, loss and head backward in one kernel; stores the gate values and d h) -> gru16_backward (reverse time, d gates in place, d x) ->
+gru16_wgrad -> trunk backward, all writing gradient slabs over the joint flat layout.
 Row indices come from SharedReplayBuffer.recurrent_rows / naive_recurrent_rows (the reference's index arithmetic,
 including chunks that straddle two series when T % L != 0)."""
 import numpy as np
@@ -29,11 +31,7 @@ class _Scratch:
         key = (L, Nc, training, tag)
         s = self._c.get(key)
         if s is None:
-            B = L * Nc
-            f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=device)
-            s = dict(featT=f(H, B))
-            if training:
-                s.update(gates=f(ops.gru_scratch_floats(L, Nc)), dxT=f(H, B), dgiT=f(3 * H, B), dghnT=f(H, B), giT=f(3 * H, B))
+            s = dict(featT=torch.empty(H, L * Nc, dtype=torch.float32, device=device))
             self._c[key] = s
         return s
 
@@ -57,7 +55,6 @@ class _Scratch:
 
 
 _scratch = _Scratch()
-_USE_GRU16 = os.environ.get("MAPPO_GRU16", "1") != "0"      # diagnostic switch while the round-2 training kernels still exist
 _TWO_STREAMS = os.environ.get("MAPPO_REC_TWO_STREAMS", "1") != "0"   # the two networks' chains on two streams (A/B: one after the other)
 
 
@@ -170,64 +167,42 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
     if epochs is not None and tr._use_valuenorm:
         vn_state = epochs[2][epochs[0]]
     n_trunk = ops.mlp_backward_slabs(B)
-    if _USE_GRU16:
-        n_bwd = ops.gru16_slabs(L, Nc)                         # rows of loss partials / slab rows the 16-sequence-tile kernels may write
-        n_slabs = max(n_trunk, n_bwd)
-    else:
-        n_bwd, n_wg = ops.gru_backward_slabs(Nc), ops.gru_wgrad_slabs(L, Nc)
-        n_slabs = max(n_trunk, n_bwd, n_wg)
+    n_bwd = ops.gru16_slabs(L, Nc)                             # rows of loss partials / slab rows the 16-sequence-tile kernels may write
+    n_slabs = max(n_trunk, n_bwd)
     P = pol.n_flat
-    sfx = "16" if _USE_GRU16 else ""
-    slabs = tr._buf("slabs_rec" + sfx, (n_slabs, P), zero=True)      # rows a kernel never writes stay zero
+    slabs = tr._buf("slabs_rec", (n_slabs, P), zero=True)      # rows a kernel never writes stay zero
     if not update_actor and not tr._actor_slabs_clean:
         slabs[:, :pol.seg_bounds[1]].zero_()
     tr._actor_slabs_clean = not update_actor
-    pa = tr._buf("partials_a" + sfx, (1024,), torch.float64, zero=True)
-    pc = tr._buf("partials_c" + sfx, (1024,), torch.float64, zero=True)
+    pa = tr._buf("partials_a", (1024,), torch.float64, zero=True)
+    pc = tr._buf("partials_c", (1024,), torch.float64, zero=True)
     nets = []
     if update_actor:
         nets.append((pol.actor, src["obs"], src["h0_a"], 1, pa, 0, "actor"))
     nets.append((pol.critic, src["share_obs"], src["h0_c"], 2, pc, pol.seg_bounds[1], "critic"))
 
-    def one_net(net, x, h0, head, part, col0, tag):
-        s = _scratch.get(dev, L, Nc, True, tag)
-        ops.mlp_features(net.flat, net.desc, x, rows, B, s["featT"])
-        # input-side products (W_ih x, W_ih^T dgi) run as plain row-tile kernels over all rows; the sequential kernels carry
-        # only the W_hh half and, without W_ih in LDS, two of their workgroups (actor's and critic's) share a CU
-        ops.gru_input_gates(net.flat, net.desc, s["featT"], B, s["giT"])
-        ops.gru_forward(net.flat, net.desc, s["featT"], h0, h0_rows, src["masks"], rows, L, Nc, scratch=s["gates"], head_mode=0,
-                        giT=s["giT"])
-        ops.gru_backward(net.flat, net.desc, s["gates"], src["masks"], rows, L, Nc, head,
-                         src["avail"] if head == 1 else None, src["actions"] if head == 1 else None,
-                         src["old_logp"] if head == 1 else None, src["adv"] if head == 1 else None, src["active"],
-                         src["v_old"] if head == 2 else None, src["returns"] if head == 2 else None,
-                         vn_state if head == 2 else None, tr._mb_moments, tr._cfg, None, s["dgiT"], s["dghnT"], slabs, P, col0, part)
-        ops.gru_input_backward(net.flat, net.desc, s["dgiT"], B, s["dxT"])
-        ops.gru_wgrad(net.desc, s["featT"], s["gates"], s["dgiT"], s["dghnT"], L, Nc, slabs, P, col0)
-        ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
+    def one_net(net, x, h0, head, part, col0, tag):          # 16-sequence-tile kernels (gru_train16.hip)
+        narrow = net.desc.in_dim <= 64 and net.desc.layer_N <= 1
+        s = _scratch.get16(dev, L, Nc, tag, narrow)
+        if narrow:
+            ops.mlp_features_seq(net.flat, net.desc, x, rows, L, Nc, s["feat"])
+        else:
+            ops.mlp_features(net.flat, net.desc, x, rows, B, s["feat"])
+        ops.gru16_forward_loss(net.flat, net.desc, s["feat"], narrow, h0, h0_rows, src["masks"], rows, L, Nc, head,
+                               src["avail"] if head == 1 else None, src["actions"] if head == 1 else None,
+                               src["old_logp"] if head == 1 else None, src["adv"] if head == 1 else None, src["active"],
+                               src["v_old"] if head == 2 else None, src["returns"] if head == 2 else None,
+                               vn_state if head == 2 else None, tr._mb_moments, tr._cfg, s["scratch"], slabs, P, col0, part)
+        ops.gru16_backward(net.flat, net.desc, src["masks"], rows, L, Nc, s["scratch"], None if narrow else s["dxT"])
+        ops.gru16_wgrad(net.desc, s["feat"], narrow, s["scratch"], L, Nc, slabs, P, col0)
+        if narrow:
+            ops.trunk_backward_seq(net.flat, net.desc, x, rows, L, Nc, s["dx"], slabs, P, col0)
+        else:
+            ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
 
-    if _USE_GRU16:
-        def one_net(net, x, h0, head, part, col0, tag):   # noqa: F811 — 16-sequence-tile kernels (gru_train16.hip)
-            narrow = net.desc.in_dim <= 64 and net.desc.layer_N <= 1
-            s = _scratch.get16(dev, L, Nc, tag, narrow)
-            if narrow:
-                ops.mlp_features_seq(net.flat, net.desc, x, rows, L, Nc, s["feat"])
-            else:
-                ops.mlp_features(net.flat, net.desc, x, rows, B, s["feat"])
-            ops.gru16_forward_loss(net.flat, net.desc, s["feat"], narrow, h0, h0_rows, src["masks"], rows, L, Nc, head,
-                                   src["avail"] if head == 1 else None, src["actions"] if head == 1 else None,
-                                   src["old_logp"] if head == 1 else None, src["adv"] if head == 1 else None, src["active"],
-                                   src["v_old"] if head == 2 else None, src["returns"] if head == 2 else None,
-                                   vn_state if head == 2 else None, tr._mb_moments, tr._cfg, s["scratch"], slabs, P, col0, part)
-            ops.gru16_backward(net.flat, net.desc, src["masks"], rows, L, Nc, s["scratch"], None if narrow else s["dxT"])
-            ops.gru16_wgrad(net.desc, s["feat"], narrow, s["scratch"], L, Nc, slabs, P, col0)
-            if narrow:
-                ops.trunk_backward_seq(net.flat, net.desc, x, rows, L, Nc, s["dx"], slabs, P, col0)
-            else:
-                ops.trunk_backward(net.flat, net.desc, x, rows, B, s["dxT"], slabs, P, col0)
-
-    # The sequential GRU kernels occupy one wave per 32 sequences (240 of the chip's 1024 SIMDs at BASELINE config 2), so
-    # the two networks' chains run side by side on two streams; they write disjoint slab columns and disjoint partials.
+    # The two networks' chains run side by side on two streams (they write disjoint slab columns and disjoint partials): at small
+    # sizes (config-2 rmappo: 120 workgroups per sequence kernel) the second chain fills the idle CUs (train 6.96 -> 4.86 ms); at
+    # config-3 size every kernel fills the chip by itself and the streams neither help nor hurt (23.0 ms either way).
     if len(nets) == 2 and _TWO_STREAMS:
         cur = torch.cuda.current_stream()
         if tr._side_stream is None:

@@ -355,47 +355,68 @@ def test_recurrent_rows_epochs_are_permutations(M):
     assert len({tuple(f) for f in firsts}) == E                      # epochs differ
 
 
-def test_gru_backward_with_dx_matches_deferred_input_backward(M):
-    """mappo_gru_backward(dxT != NULL) == mappo_gru_backward(dxT = NULL) followed by mappo_gru_input_backward, bit for bit
-    (same kernels; the call only appends the W_ih^T product), on a forward pass without / with precomputed input gates."""
+def test_gru16_blocked_and_feature_major_paths_agree(M):
+    """The 16-sequence-tile training kernels (csrc/gru_train16.hip) take the trunk features either BLOCKED per (t, 16 sequences)
+    tile (narrow inputs: mappo_mlp_features_seq, d x left blocked for mappo_trunk_backward_seq) or feature-major [64][B] (wide
+    inputs: mappo_mlp_features, d x to dxT for mappo_trunk_backward).  Both forms, on the same critic and rows (Nc = 37: a ragged
+    last tile; gathered rows), must give the same loss partials, head / rnn.norm / GRU gradient columns and d x."""
     from mappo_amd import ops
-    a = make_args(M, use_recurrent_policy=True, algorithm_name="rmappo")
-    pol = M.R_MAPPOPolicy(a, [18], [54], M.Discrete(5))
+    T, N, Ma, D, S, A, L = 20, 37, 1, 30, 48, 9, 10
+    a = make_args(M, episode_length=T, n_rollout_threads=N, use_recurrent_policy=True, data_chunk_length=L)
+    torch.manual_seed(2)
+    pol = M.R_MAPPOPolicy(a, [D], [S], M.Discrete(A))
     tr = M.R_MAPPO(a, pol)
-    net, L, Nc, H = pol.critic, 5, 70, 64
+    net = pol.critic
+    H = 64
+    Nc = 37
     B = L * Nc
-    g = torch.Generator(device="cuda").manual_seed(11)
+    g = torch.Generator(device="cuda").manual_seed(6)
     rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
-    featT, h0 = rnd(H, B), rnd(Nc, H)
-    masks = (torch.rand(B, device="cuda", generator=g) > 0.2).float()
-    active, v_old, ret = torch.ones(B, device="cuda"), rnd(B), rnd(B)
-    tr._mb_moments.copy_(torch.tensor([float(ret.sum()), float((ret * ret).sum()), float(B), float(B)], dtype=torch.float64))
-    vn = torch.tensor([0.1, 1.3, 0.9], device="cuda")
+    n_buf = B + 50
+    x = rnd(n_buf, S)
+    rows = torch.randperm(n_buf, device="cuda", generator=g)[:B].to(torch.int32).contiguous()
+    h0, h0_rows = rnd(n_buf, H), torch.randperm(n_buf, device="cuda", generator=g)[:Nc].to(torch.int32).contiguous()
+    masks = (torch.rand(n_buf, device="cuda", generator=g) > 0.2).float()
+    active = (torch.rand(n_buf, device="cuda", generator=g) > 0.2).float()
+    v_old, ret = rnd(n_buf) * 0.3, rnd(n_buf) * 2
+    vn = torch.tensor([0.1, 1.3, 1.0], device="cuda")
+    mom = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ops.minibatch_moments(ret, active, rows, B, mom)
     P = pol.n_flat
-    n_slabs = ops.gru_backward_slabs(Nc)
+    n_sl = max(ops.gru16_slabs(L, Nc), ops.mlp_backward_slabs(B))
+    col0 = pol.seg_bounds[1]
     outs = []
-    for pre_gi in (False, True):
-        for with_dx in (True, False):
-            scratch = torch.empty(ops.gru_scratch_floats(L, Nc), device="cuda")
-            giT = torch.empty(3 * H, B, device="cuda") if pre_gi else None
-            if pre_gi:
-                ops.gru_input_gates(net.flat, net.desc, featT, B, giT)
-            ops.gru_forward(net.flat, net.desc, featT, h0, None, masks, None, L, Nc, scratch=scratch, head_mode=0, giT=giT)
-            dxT, dgiT, dghnT = torch.zeros(H, B, device="cuda"), torch.empty(3 * H, B, device="cuda"), torch.empty(H, B, device="cuda")
-            slabs = torch.zeros(n_slabs, P, device="cuda")
-            part = torch.zeros(4 * n_slabs, dtype=torch.float64, device="cuda")
-            ops.gru_backward(net.flat, net.desc, scratch, masks, None, L, Nc, 2, None, None, None, None, active, v_old, ret, vn,
-                             tr._mb_moments, tr._cfg, dxT if with_dx else None, dgiT, dghnT, slabs, P, pol.seg_bounds[1], part)
-            if not with_dx:
-                ops.gru_input_backward(net.flat, net.desc, dgiT, B, dxT)
-            outs.append([t.cpu().numpy() for t in (dxT, dgiT, dghnT, slabs, part)])
-    assert np.abs(outs[0][0]).max() > 0
-    for other in outs[1:]:
-        for x, y in zip(outs[0][:3], other[:3]):
-            np.testing.assert_allclose(y, x, rtol=2e-5, atol=2e-6)          # in-kernel vs precomputed W_ih x: summation order
-    for k in (0, 2):
-        for x, y in zip(outs[k], outs[k + 1]):
-            np.testing.assert_array_equal(y, x)                             # with / without dxT: identical
+    for blocked in (True, False):
+        scratch = torch.zeros(ops.gru16_scratch_floats(L, Nc), device="cuda")
+        comp = ops.gru16_blocked_floats(L, Nc)
+        slabs = torch.zeros(n_sl, P, device="cuda")
+        part = torch.zeros(1024, dtype=torch.float64, device="cuda")
+        if blocked:
+            feat = torch.empty(comp, device="cuda")
+            ops.mlp_features_seq(net.flat, net.desc, x, rows, L, Nc, feat)
+            dxT = None
+        else:
+            feat = torch.empty(H, B, device="cuda")
+            ops.mlp_features(net.flat, net.desc, x, rows, B, feat)
+            dxT = torch.zeros(H, B, device="cuda")
+        ops.gru16_forward_loss(net.flat, net.desc, feat, blocked, h0, h0_rows, masks, rows, L, Nc, 2, None, None, None, None, active, v_old,
+                               ret, vn, mom, tr._cfg, scratch, slabs, P, col0, part)
+        ops.gru16_backward(net.flat, net.desc, masks, rows, L, Nc, scratch, dxT)
+        ops.gru16_wgrad(net.desc, feat, blocked, scratch, L, Nc, slabs, P, col0)
+        if blocked:
+            ops.trunk_backward_seq(net.flat, net.desc, x, rows, L, Nc, scratch[5 * comp:6 * comp], slabs, P, col0)
+            # blocked d x -> feature-major for the comparison: [L][n_ct][4 b][16 q... lane][4 i] -> feature 16 b + 4 q + i, sequence 16 j + n
+            n_ct = (Nc + 15) // 16
+            d = scratch[5 * comp:6 * comp].view(L, n_ct, 4, 4, 16, 4)            # t, j, b, q, n, i
+            dxT = d.permute(2, 3, 5, 0, 1, 4).reshape(H, L, n_ct * 16)[:, :, :Nc].reshape(H, B)
+        else:
+            ops.trunk_backward(net.flat, net.desc, x, rows, B, dxT, slabs, P, col0)
+        outs.append((dxT.cpu().numpy(), slabs.double().sum(0).cpu().numpy(), part.cpu().numpy()))
+    (dx_b, g_b, p_b), (dx_f, g_f, p_f) = outs
+    np.testing.assert_allclose(p_b, p_f, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(dx_b, dx_f, rtol=0, atol=2e-6 * np.abs(dx_f).max())
+    np.testing.assert_allclose(g_b, g_f, rtol=0, atol=1e-5 * np.abs(g_f).max())
+    assert np.abs(g_f).max() > 0 and np.abs(dx_f).max() > 0
 
 
 @pytest.mark.parametrize("Do,Ds,A,R", [(30, 48, 9, 3 * 37 + 5), (176, 322, 18, 640), (130, 70, 5, 37)])
