@@ -130,10 +130,16 @@ class R_MAPPOPolicy:
         return actions, rnn_states_actor
 
     # ---- one-launch rollout step (mappo_rollout_step) ----------------------------------------------------------
-    def can_fuse_step(self):
+    def can_dual_update(self):
+        """Both networks' PPO update in one launch (mappo_actor_critic_update): narrow inputs only."""
         a, c = self.actor.desc, self.critic.desc
         return (not a.recurrent and not c.recurrent and a.in_dim <= 64 and c.in_dim <= 64 and a.layer_N == c.layer_N
                 and a.use_relu == c.use_relu)
+
+    def can_fuse_step(self):
+        a, c = self.actor.desc, self.critic.desc
+        same_class = (a.in_dim <= 64) == (c.in_dim <= 64) and max(a.in_dim, c.in_dim) <= 512       # both narrow or both wide
+        return (not a.recurrent and not c.recurrent and same_class and a.layer_N == c.layer_N and a.use_relu == c.use_relu)
 
     @torch.no_grad()
     def collect_step_fused(self, buffer, step, pending=None, centralized=True, use_available_actions=False, deterministic=False,

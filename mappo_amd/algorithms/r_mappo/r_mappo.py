@@ -183,7 +183,7 @@ class R_MAPPO():
                                   src["active"], vn_state, self._mb_moments, cfg, slabs, P, pol.seg_bounds[1], pc, nc)
                 cur.wait_stream(side)
                 n_pa, n_pc = na, nc
-            elif update_actor and self._dual_update and pol.can_fuse_step():
+            elif update_actor and self._dual_update and pol.can_dual_update():
                 # both networks in ONE launch, half the CUs each (mappo_actor_critic_update): one ragged tail instead of two
                 ops.actor_critic_update(pol.actor.flat, pol.actor.desc, src["obs"], pol.critic.flat, pol.critic.desc, src["share_obs"],
                                         rows, B, src["avail"], src["actions"], src["old_logp"], src["adv"], src["active"], src["v_old"],
@@ -361,7 +361,7 @@ class R_MAPPO():
         if self._epochs is not None:
             # (rows of loss partials the update kernels wrote; not taken from a side effect of _update_kernels: under data
             # parallelism the epochs may have been graph replays, during which no Python runs)
-            n_rows = ops.dual_update_slabs(self.policy.actor.desc, self.policy.critic.desc, S) if (update_actor and self._dual_update and self.policy.can_fuse_step()) \
+            n_rows = ops.dual_update_slabs(self.policy.actor.desc, self.policy.critic.desc, S) if (update_actor and self._dual_update and self.policy.can_dual_update()) \
                 else ops.mlp_backward_slabs(S)
             ops.update_stats(self._pa if update_actor else None, n_rows, self._pc, n_rows, self._mb_moments, self._cfg, self._stats,
                              self._acc)

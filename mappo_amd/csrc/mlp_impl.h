@@ -1302,6 +1302,9 @@ int wide16_launch_forward_r(int mode, int ln, dim3 grid, dim3 block, size_t lds_
 template <bool R>
 int wide16_launch_features_dual_r(int ln, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
                                   const Wide16Args &wc, const FwdArgs &c, int nA);
+template <bool R>
+int wide16_launch_rollout_step_r(int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                 const Wide16Args &wc, const FwdArgs &c, int nA);
 // split-K variants (one tile per 4-wave workgroup): step-sized batches
 int wide16_launch_forward_sk(int mode, bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a,
                              const char *who);
@@ -1387,6 +1390,26 @@ int wide16_launch_features_dual_r(int ln, dim3 grid, dim3 block, size_t lds_byte
 }
 template int wide16_launch_features_dual_r<MLP_WIDE_RELU>(int, dim3, dim3, size_t, hipStream_t, const Wide16Args &, const FwdArgs &,
                                                           const Wide16Args &, const FwdArgs &, int);
+
+template <bool R, int L, int NCH>
+static int wide16_rollout_step_one(dim3 grid, size_t lds_bytes, hipStream_t st, const WideStepArgs &s) {
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_rollout_step_kernel<R, L, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(96 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("rollout_step: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  PROF_LAUNCH(MAPPO_PROF_ACT, (wide_rollout_step_kernel<R, L, NCH>), grid, dim3(512), lds_bytes, st, s);
+  return MAPPO_OK;
+}
+template <bool R>
+int wide16_launch_rollout_step_r(int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                 const Wide16Args &wc, const FwdArgs &c, int nA) {
+  WideStepArgs s;
+  s.wa = wa; s.wc = wc; s.a = a; s.c = c; s.nA = nA;
+  const bool big = wa.D > 256 || wc.D > 256;                      // row-block registers for 8 chunks instead of 4
+  if (ln == 0) return big ? wide16_rollout_step_one<R, 0, 8>(grid, lds_bytes, st, s) : wide16_rollout_step_one<R, 0, 4>(grid, lds_bytes, st, s);
+  if (ln == 1) return big ? wide16_rollout_step_one<R, 1, 8>(grid, lds_bytes, st, s) : wide16_rollout_step_one<R, 1, 4>(grid, lds_bytes, st, s);
+  return big ? wide16_rollout_step_one<R, 2, 8>(grid, lds_bytes, st, s) : wide16_rollout_step_one<R, 2, 4>(grid, lds_bytes, st, s);
+}
+template int wide16_launch_rollout_step_r<MLP_WIDE_RELU>(int, dim3, size_t, hipStream_t, const Wide16Args &, const FwdArgs &, const Wide16Args &,
+                                                         const FwdArgs &, int);
 #endif
 
 #ifdef MLP_TU_WIDE_SK
@@ -1804,7 +1827,8 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
                                   float *mask_dst, int32_t centralized, mappo_stream_t stream) {
   if (int rc = check_desc(actor_desc, "rollout_step")) return rc;
   if (int rc = check_desc(critic_desc, "rollout_step")) return rc;
-  MAPPO_REQUIRE(actor_desc->in_dim <= MAXD && critic_desc->in_dim <= MAXD, "rollout_step: in_dim > %d goes through the separate kernels", MAXD);
+  MAPPO_REQUIRE((actor_desc->in_dim <= MAXD) == (critic_desc->in_dim <= MAXD) && actor_desc->in_dim <= 512 && critic_desc->in_dim <= 512,
+                "rollout_step: both networks narrow (in_dim <= %d) or both wide (<= 512)", MAXD);
   MAPPO_REQUIRE(actor_desc->layer_N == critic_desc->layer_N && actor_desc->use_relu == critic_desc->use_relu,
                 "rollout_step: actor and critic must share layer_N and the activation");
   MAPPO_REQUIRE(critic_desc->out_dim == 1, "rollout_step: critic out_dim must be 1");
@@ -1813,6 +1837,38 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
   MAPPO_REQUIRE(M > 0 || !obs_dst, "rollout_step: the fused insert needs the (thread, agent) row layout (M > 0)");
   MAPPO_REQUIRE(!obs_dst || (share_dst && rewards && dones && rew_dst && mask_dst && B % M == 0), "rollout_step: incomplete insert arguments");
   MAPPO_CLEAR_STICKY();
+  if (actor_desc->in_dim > MAXD) {
+    // Wide inputs: the insert is its own (HBM-bound: it moves the rows it copies once in, twice out) launch, the two networks share
+    // one (wide_rollout_step_kernel: every CU busy for one chunk-latency chain instead of half the chip for two).
+    if (obs_dst)
+      if (int rci = mappo_insert_mpe(obs, obs_stride_n, obs_stride_m, rewards, rew_stride_n, rew_stride_m, dones, done_stride_n, done_stride_m,
+                                     obs_dst, share_dst, rew_dst, mask_dst, (int32_t)(B / M), M, actor_desc->in_dim, centralized, stream))
+        return rci;
+    FwdArgs a = {}, c = {};
+    a.params = actor_params; a.x = obs; a.avail = avail; a.actions = actions; a.logp = logp; a.desc = *actor_desc; a.B = B;
+    a.deterministic = deterministic; a.seed = seed; a.counter = counter; a.counter_dev = counter_dev;
+    a.off = net_offsets(a.desc); a.map = lds_map(a.desc, 8);
+    c.params = critic_params; c.x = share_obs; c.out = values; c.desc = *critic_desc; c.B = B; c.off = net_offsets(c.desc); c.map = lds_map(c.desc, 8);
+    Wide16Args wa, wc;
+    size_t lba, lbc;
+    dim3 ga, gc, ba, bc;
+    bool sa, sc;
+    if (int rcp = wide_forward_prepare(a, wa, lba, ga, ba, sa, "rollout_step")) return rcp;
+    if (int rcp = wide_forward_prepare(c, wc, lbc, gc, bc, sc, "rollout_step")) return rcp;
+    wa.x_M = M; wa.x_sn = obs_stride_n; wa.x_sm = obs_stride_m;
+    wc.x_M = M; wc.x_sn = share_stride_n; wc.x_sm = share_stride_m;
+    // each network: one workgroup per 8 tiles, at most half of the chip's CUs
+    const int64_t n_groups = ((B + 15) / 16 + 7) / 8;
+    const int nb = (int)(n_groups < NUM_CU / 2 ? n_groups : NUM_CU / 2);
+    const int nA = actions ? nb : 0;
+    const dim3 grid((unsigned)(nA + nb));
+    const size_t lb = lba > lbc ? lba : lbc;
+    const int rcw = actor_desc->use_relu ? wide16_launch_rollout_step_r<true>(actor_desc->layer_N, grid, lb, as_stream(stream), wa, a, wc, c, nA)
+                                         : wide16_launch_rollout_step_r<false>(actor_desc->layer_N, grid, lb, as_stream(stream), wa, a, wc, c, nA);
+    if (rcw) return rcw;
+    MAPPO_CHECK_LAUNCH("rollout_step");
+    return MAPPO_OK;
+  }
   const int64_t n_tiles = (B + 15) / 16;                 // forward16_body: 16 samples per wave
   const int want = n_tiles >= 4 ? 4 : (n_tiles >= 2 ? 2 : 1);
   int nw = fit_waves(*actor_desc, want);

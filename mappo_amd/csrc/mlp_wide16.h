@@ -153,7 +153,7 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
   auto row_ptr = [&](int64_t grp) {
     const int64_t i = (grp * NW + wave) * 16 + n;
     const int64_t row = i < p.B ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
-    return p.x + row * D;
+    return p.x + (p.x_M ? (row / p.x_M) * p.x_sn + (row % p.x_M) * p.x_sm : row * D);
   };
   f32x4 xq[NCH][4];                                           // the row block: xq[c][j4][t] = column 64 c + 16 j4 + 4 q + t (a row's 64 B per load)
   auto load_rows = [&](const float *xr, int c) {              // raw (ld4_row_fix is applied to the last chunk when the tile starts)
@@ -496,6 +496,20 @@ __global__ __launch_bounds__(64 * NW, 2) void wide_forward16_kernel(Wide16Args w
   __shared__ __align__(16) float sW[2][HID * RS16];
   __shared__ __align__(16) float sB[HID];
   wide_forward16_body<RELU, LN, MODE, NW, NCH>(w, p, lds, sW, sB, blockIdx.x, gridDim.x);
+}
+
+// get_actions of the actor AND get_values of the critic in one launch (mpe_runner.py:95-109 for MLP policies with wide inputs):
+// workgroups [0, nA) the actor (sampling), [nA, nA + nC) the critic.  As two launches — even on two streams inside the captured
+// episode — each network's 8-tile groups occupied half of the chip's CUs for the length of its chunk-latency chain, one after
+// the other (45 + 49 us per step at BASELINE configs[4]).
+struct WideStepArgs { Wide16Args wa, wc; FwdArgs a, c; int nA; };
+template <bool RELU, int LN, int NCH>
+__global__ __launch_bounds__(512, 2) void wide_rollout_step_kernel(WideStepArgs s) {
+  extern __shared__ __align__(16) float lds[];
+  __shared__ __align__(16) float sW[2][HID * RS16];
+  __shared__ __align__(16) float sB[HID];
+  if ((int)blockIdx.x < s.nA) wide_forward16_body<RELU, LN, 1, 8, NCH>(s.wa, s.a, lds, sW, sB, blockIdx.x, s.nA);
+  else wide_forward16_body<RELU, LN, 0, 8, NCH>(s.wc, s.c, lds, sW, sB, (int)blockIdx.x - s.nA, (int)gridDim.x - s.nA);
 }
 
 // Trunk features of a recurrent actor AND critic with wide inputs in one launch (rollout step: the two networks read different

@@ -9,6 +9,10 @@ struct Wide16Args {
   float *mean0, *rstd0;      // [B] each (may be NULL: rollout forward)
   int64_t B;
   int D, w1, b1, fn_w, fn_b; // offsets into params (fn_* < 0: no feature norm)
+  // streamed rollout forward only (wide16_layer1): x_M > 0 = strided source rows, sample i = (n, m) = (i / x_M, i % x_M) starts at
+  // x[n * x_sn + m * x_sm] — the env's output read in place (mappo_rollout_step); x_M == 0: contiguous rows x[i * D]
+  int x_M;
+  int64_t x_sn, x_sm;
 };
 
 

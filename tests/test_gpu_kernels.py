@@ -772,7 +772,10 @@ def test_rollout_step_values_only_and_copy_batch(ops):
 
 
 @pytest.mark.parametrize("Da,Dc,A,LN,relu,fnorm,R", [(1, 1, 1, 1, True, True, 5), (64, 64, 32, 2, False, False, 130), (33, 7, 9, 0, True, True, 47),
-                                                      (18, 54, 5, 1, False, True, 3072), (20, 60, 17, 2, True, False, 16)])
+                                                      (18, 54, 5, 1, False, True, 3072), (20, 60, 17, 2, True, False, 16),
+                                                      # wide inputs (both networks 65..512): wide_rollout_step_kernel, the two networks by
+                                                      # workgroup role; widths that are not multiples of 4, ragged last tile, > 8 tiles
+                                                      (512, 512, 5, 1, True, True, 4100), (130, 70, 9, 0, False, True, 37), (176, 322, 18, 2, True, False, 300)])
 def test_rollout_step_shapes_vs_forward_kernels(ops, Da, Dc, A, LN, relu, fnorm, R):
     """The 16x16x4 step kernel against mlp_forward / actor_act over network shapes (odd / maximal widths, partial tiles,
     tanh, no feature norm): values and deterministic log-probs to fp32 rounding, argmax actions equal unless two logits tie
