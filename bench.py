@@ -18,7 +18,8 @@ Rank 0 prints ONE JSON line.  Extra objects:
   roofline     : the dominant kernel of the step — mlp_update16_dual_kernel: forward + PPO / value loss + backward of the
                  actor AND critic MLPs in one launch, bound by the fp32 MFMA rate; algorithmic flops 6*MACs/sample
                  (forward, dW, dX) / launch duration from HIP events attached to the dispatch.  `traffic` = HBM bytes per
-                 launch from the committed rocprofv3 PMC passes over this very kernel (profiles/r02/dual_update_hbm_pmc.json).
+                 launch from the committed rocprofv3 PMC passes over this very kernel (profiles/r03/dual_update_hbm_pmc.json,
+                 keyed by a hash of the kernel's sources: a stale measurement is reported as null).
   gae_roofline : the GAE scan kernel at BASELINE configs[4] per-GPU size (T=400, R=16 384: 105 MB), HBM-bound.
   ppo_loss_roofline : the standalone fused PPO loss kernel (mappo_ppo_loss_fwd_bwd, north_star's HBM-roofline kernel)
                  on this step's buffer and at BASELINE configs[4] size: 4*(3A+8) B/sample / launch duration.
@@ -39,7 +40,18 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32, dense fp32 matrix peak
-HBM_PMC_FILE = os.path.join(ROOT, "profiles", "r02", "dual_update_hbm_pmc.json")   # scripts/pmc_hbm.sh: FETCH_SIZE / WRITE_SIZE passes
+HBM_PMC_FILE = os.path.join(ROOT, "profiles", "r03", "dual_update_hbm_pmc.json")   # scripts/pmc_hbm.sh: FETCH_SIZE / WRITE_SIZE passes
+
+
+def kernel_source_sha256():
+    """Hash of the sources the dominant kernel is compiled from (same recipe as scripts/pmc_hbm.sh): the committed PMC traffic is
+    only reported while it describes the kernel that is actually running."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("mlp_upd16.h", "mlp_core.h", "common.h"):
+        with open(os.path.join(ROOT, "mappo_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def measured_traffic(kernel, samples):
@@ -53,6 +65,11 @@ def measured_traffic(kernel, samples):
         return None, "no PMC summary committed"
     if m.get("kernel") != kernel or int(m.get("samples", -1)) != int(samples):
         return None, f"PMC summary is for {m.get('kernel')} at {m.get('samples')} samples"
+    try:
+        if m.get("source_sha256") != kernel_source_sha256():
+            return None, "PMC summary is stale: the kernel's sources changed since scripts/pmc_hbm.sh measured it"
+    except OSError:
+        return None, "kernel sources not found: cannot tell whether the PMC summary is current"
     return int(m["traffic_bytes"]), m.get("note", "")
 
 
@@ -280,7 +297,7 @@ def main_c4(ns, world, rank, device, result_out, force_dp):
     a.gain = 1.0                                               # train_smac.sh
     a.seed = 1
     torch.manual_seed(a.seed)
-    env = SyntheticSMACEnv(a.n_rollout_threads, M, D, S, A, seed=1 + rank, device=device)
+    env = SyntheticSMACEnv(a.n_rollout_threads, M, D, S, A, seed=1 + rank, device=device, pool_steps=a.episode_length)
     dp = DataParallel() if (world > 1 or force_dp) else None
     runner = SMACRunner(dict(all_args=a, envs=env, eval_envs=None, num_agents=M, device=device, run_dir=None, dist_group=dp))
     runner.warmup()

@@ -295,6 +295,22 @@ int mappo_recurrent_step_dual(const float *actor_params, const mappo_net_desc *a
                               float *critic_h_last, const float *masks, int32_t Nc, const float *avail, int32_t deterministic,
                               uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions, float *logp,
                               float *values, mappo_stream_t stream);
+/* The SMAC rollout step in ONE launch (smac_runner.py:110-151 across two consecutive steps): the insert of the env output of step
+ * k - 1 into buffer slot k (what mappo_insert_smac does: slot copies, masks / active_masks / bad_masks, states x (1 - env done)) AND
+ * get_actions / get_values of step k, reading that env output (obs [N*M][D], share_obs [N*M][S], avail [N*M][A] or NULL, contiguous)
+ * and the states the step before returned (actor_h / critic_h [N*M][64], unmasked) in place; the row mask is derived from `dones`
+ * exactly as masks[k] is.  Next states go to *_h_next (not aliasing *_h); actions / logp / values are slot k's arrays. */
+typedef struct mappo_smac_slot {
+  float *obs, *share_obs, *available_actions /*or NULL*/, *rewards /*slot k - 1*/, *masks, *bad_masks, *active_masks, *rnn_states,
+        *rnn_states_critic;
+} mappo_smac_slot;
+int mappo_recurrent_rollout_step(const float *actor_params, const mappo_net_desc *actor_desc /*host*/, const float *critic_params,
+                                 const mappo_net_desc *critic_desc /*host*/, const float *obs, const float *share_obs, const float *avail,
+                                 const float *rewards, int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones,
+                                 int64_t done_stride_n, int64_t done_stride_m, const uint8_t *bad_transition /*[N*M] or NULL*/,
+                                 const float *actor_h, const float *critic_h, float *actor_h_next, float *critic_h_next, int32_t N, int32_t M,
+                                 int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
+                                 float *logp, float *values, const mappo_smac_slot *dst /*host*/, mappo_stream_t stream);
 /* Trunk features of two networks (same layer_N / activation, in_dim <= 64) on the same B rows in one launch. */
 int mappo_mlp_features_dual(const float *params_a, const mappo_net_desc *desc_a /*host*/, const float *x_a, float *featT_a,
                             const float *params_c, const mappo_net_desc *desc_c /*host*/, const float *x_c, float *featT_c,
@@ -378,6 +394,11 @@ int mappo_mpe_spread_step(double *agent_pos, double *agent_vel, double *landmark
  * produces data of the SMAC shapes with agents that die and episodes that end.  obs [N][M][D], share_obs [N][M][S] ~ N(0,1);
  * avail [N][M][A] in {0,1}; rewards [N]; dead (state) / dones [N][M] bool bytes; counter_dev [34] = {counter, 33 tickets}:
  * counter keys the Philox stream and is advanced by the launch itself (last workgroup to finish), tickets must start at 0. */
+/* P consecutive steps in one launch (pools [P][N][M][D] ... [P][N][M]; step p uses counter + p, the launch advances the counter by P):
+ * the env hands the pool out step by step as views, as SyntheticMPEEnv does with its per-episode block. */
+int mappo_synth_smac_pool(float *obs, float *share_obs, float *avail, float *rewards, uint8_t *dead, uint8_t *dones, int32_t P,
+                          int32_t N, int32_t M, int32_t D, int32_t S, int32_t A, float p_death, float p_term, uint64_t seed,
+                          uint64_t *counter_dev /*[34]*/, mappo_stream_t stream);
 int mappo_synth_smac_step(float *obs, float *share_obs, float *avail, float *rewards, uint8_t *dead, uint8_t *dones,
                           int32_t N, int32_t M, int32_t D, int32_t S, int32_t A, float p_death, float p_term,
                           uint64_t seed, uint64_t *counter_dev /*[34]*/, mappo_stream_t stream);

@@ -26,6 +26,12 @@ class PpoCfg(C.Structure):
                 ("use_valuenorm", C.c_int32), ("accumulate_partials", C.c_int32)]
 
 
+class SmacSlot(C.Structure):
+    """mappo_smac_slot: destination arrays of one buffer slot for the fused SMAC insert (include/mappo_hip.h)."""
+    _fields_ = [(n, C.c_void_p) for n in ("obs", "share_obs", "available_actions", "rewards", "masks", "bad_masks", "active_masks",
+                                          "rnn_states", "rnn_states_critic")]
+
+
 _P, _I32, _I64, _F, _D, _U64 = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
 # name -> (restype, argtypes); must list every symbol include/mappo_hip.h declares (tests/test_capi_symbols.py)
@@ -84,6 +90,8 @@ SIGNATURES = {
     "mappo_gru16_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _P]),
     "mappo_gru16_wgrad": (C.c_int, [C.POINTER(NetDesc), _P, _I32, _P, _I32, _I32, _P, _I64, _I64, _P]),
     "mappo_trunk_backward_seq": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _I64, _I64, _P]),
+    "mappo_recurrent_rollout_step": (C.c_int, [_P, C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P,
+                                               _P, _P, _P, _P, _I32, _I32, _I32, _U64, _U64, _P, _P, _P, _P, C.POINTER(SmacSlot), _P]),
     "mappo_mlp_features_dual": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, C.POINTER(NetDesc), _P, _P, _I64, _P]),
     "mappo_trunk_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I64, _P, _P, _I64, _I64, _P, _P]),
     "mappo_optim_workspace_bytes": (_I64, [_I64]),
@@ -91,6 +99,7 @@ SIGNATURES = {
     "mappo_clip_adam": (C.c_int, [_P, _P, _P, _P, C.POINTER(_I64), _I32, _P, _P, _P, _P, _P, _P]),
     "mappo_reduce_clip_adam": (C.c_int, [_P, _I32, _I64, _P, _P, _P, _P, C.POINTER(_I64), _I32, _P, _P, _P, _P, _P, _P]),
     "mappo_mpe_spread_reset": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _U64, _P]),
+    "mappo_synth_smac_pool": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, C.c_float, C.c_float, _U64, _P, _P]),
     "mappo_synth_smac_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, C.c_float, C.c_float, _U64, _P, _P]),
     "mappo_mpe_spread_step": (C.c_int, [_P, _P, _P, _P, _P, _P, _I32, _P, _P, _P, _I32, _I32, _I32, _I32, _U64, _P]),
     "mappo_profile_arm": (C.c_int, [_I32, _P, _P]),

@@ -189,6 +189,52 @@ class R_MAPPOPolicy:
                          buffer.action_log_probs[step].view(R), buffer.value_preds[step].view(R), insert)
         return buffer.actions[step]
 
+    # ---- recurrent policies, SMAC-style envs: insert of the previous env output + this step's get_actions in one launch ----
+    def can_fuse_recurrent_step(self, n_rows):
+        from mappo_amd import recurrent
+        if not (getattr(self.actor, "_recurrent", False) and getattr(self.critic, "_recurrent", False)):
+            return False
+        if not recurrent.can_step_dual(self.actor, self.critic):
+            return False
+        a, c = self.actor.desc, self.critic.desc
+        if max(a.in_dim, c.in_dim) <= 64:
+            return a.layer_N <= 1 and n_rows <= 1024
+        return min(a.in_dim, c.in_dim) > 64 and n_rows <= 16 * 1024
+
+    @torch.no_grad()
+    def collect_step_fused_recurrent(self, buffer, step, pending, deterministic=False):
+        """mappo_recurrent_rollout_step: `pending` = (obs, share_obs, rewards, dones, bad_transition, available_actions, rnn_states,
+        rnn_states_critic) — what the env returned for step - 1 and the states that step's get_actions returned — is inserted into
+        buffer slot `step` (smac_runner.py:129-151) by some workgroups while the others run get_actions / get_values of `step` on
+        it in place.  Returns (actions view [N, M, 1], next actor states, next critic states), or None when `pending` does not have
+        the device layout the kernel reads (the caller then inserts and collects separately)."""
+        obs, share_obs, rewards, dones, bad, avail, rnn_a, rnn_c = pending
+        b = buffer
+        dev, N, M = b.device, b.n_rollout_threads, b.num_agents
+        R = N * M
+        f32 = lambda t, d: (torch.is_tensor(t) and t.device == dev and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 3
+                            and tuple(t.shape) == (N, M, d))
+        ok = (f32(obs, b.obs.shape[-1]) and f32(share_obs, b.share_obs.shape[-1]) and torch.is_tensor(rewards) and rewards.device == dev
+              and rewards.dtype == torch.float32 and rewards.dim() in (2, 3) and torch.is_tensor(dones) and dones.device == dev
+              and dones.dtype == torch.bool and dones.dim() == 2
+              and (bad is None or (torch.is_tensor(bad) and bad.device == dev and bad.dtype == torch.bool and bad.is_contiguous()
+                                   and bad.numel() == R))
+              and (avail is None or (b.available_actions is not None and f32(avail, b.available_actions.shape[-1])))
+              and torch.is_tensor(rnn_a) and torch.is_tensor(rnn_c) and rnn_a.is_contiguous() and rnn_c.is_contiguous()
+              and rnn_a.numel() == R * 64 and rnn_c.numel() == R * 64 and b.recurrent_N == 1 and step == b.step + 1)
+        if not ok:
+            return None
+        ha = torch.empty(R, 1, 64, dtype=torch.float32, device=dev)
+        hc = torch.empty(R, 1, 64, dtype=torch.float32, device=dev)
+        slot = dict(obs=b.obs[step], share_obs=b.share_obs[step], available_actions=b.available_actions[step] if avail is not None else None,
+                    rewards=b.rewards[step - 1], masks=b.masks[step], bad_masks=b.bad_masks[step], active_masks=b.active_masks[step],
+                    rnn_states=b.rnn_states[step], rnn_states_critic=b.rnn_states_critic[step])
+        ops.recurrent_rollout_step(self.actor.flat, self.actor.desc, self.critic.flat, self.critic.desc, obs, share_obs, avail, rewards, dones,
+                                   bad, rnn_a, rnn_c, ha, hc, deterministic, self.actor._seed, step, self.actor._counter_dev,
+                                   b.actions[step].view(R), b.action_log_probs[step].view(R), b.value_preds[step].view(R), slot)
+        b.step = step % b.episode_length
+        return b.actions[step], ha, hc
+
     # ---- fused rollout step (K8 subsumes K1): outputs land in buffer slot `step` ------------------------------
     @torch.no_grad()
     def collect_into(self, buffer, step, use_available_actions=False, deterministic=False):

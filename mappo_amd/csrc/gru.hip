@@ -14,6 +14,7 @@
 #include "mlp_core.h"
 #include "mlp_trunk16r.h"
 #include "gru_step3.h"
+#include "insert_core.h"
 
 // stage W[g][k] (row-major [192][64]) -> dst[k*GS + g]; batched unconditional 16-byte loads
 __device__ __forceinline__ void stage_gru_weight(float *dst, const float *__restrict__ src) {
@@ -245,6 +246,15 @@ __global__ __launch_bounds__(256, 1) void gru_fwd_kernel(GruFwdArgs p) {
   }
 }
 
+// the same with the SMAC insert of the env output the rows are read from as a third workgroup role (mappo_recurrent_rollout_step)
+template <int TR, int TLN>
+__global__ __launch_bounds__(256, 1) void gru_step3f_dual_ins_kernel(GruFwdArgs a, GruFwdArgs c, int nA, SmacInsert ins, int nI) {
+  __shared__ Step3Shared sh;
+  if ((int)blockIdx.x < nA) gru_step3_body<2, TR, TLN>(a, sh, blockIdx.x, nA);
+  else if ((int)blockIdx.x < 2 * nA) gru_step3_body<1, TR, TLN>(c, sh, blockIdx.x - nA, nA);
+  else insert_smac_body(ins, (int)blockIdx.x - 2 * nA, nI);
+}
+
 template <int HM>
 __global__ __launch_bounds__(256, 1) void gru_step3_kernel(GruFwdArgs p) {
   __shared__ Step3Shared sh;
@@ -362,7 +372,7 @@ int mappo_recurrent_step_dual_wide_(const float *actor_params, const mappo_net_d
                                     float *actor_h_last, const float *critic_params, const mappo_net_desc *critic_desc, const float *share_obs,
                                     const float *critic_h0, float *critic_h_last, const float *masks, int32_t Nc, const float *avail,
                                     int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
-                                    float *logp, float *values, mappo_stream_t stream);      // mlp.hip
+                                    float *logp, float *values, const SmacInsert *ins, mappo_stream_t stream);      // mlp.hip
 // One rollout step of a recurrent actor and critic, trunk included: obs / share_obs rows -> actions, log-probs,
 // values, next states (r_actor_critic.py:43-70,146-165 for both networks on the same rows).
 extern "C" int mappo_recurrent_step_dual(const float *actor_params, const mappo_net_desc *actor_desc, const float *obs,
@@ -380,7 +390,8 @@ extern "C" int mappo_recurrent_step_dual(const float *actor_params, const mappo_
                 "recurrent_step_dual: the networks must share layer_N and the activation");
   if (actor_desc->in_dim > 64 && critic_desc->in_dim > 64)       // wide inputs: split-K trunks + GRU step in one launch (mlp_wide16.h)
     return mappo_recurrent_step_dual_wide_(actor_params, actor_desc, obs, actor_h0, actor_h_last, critic_params, critic_desc, share_obs, critic_h0,
-                                           critic_h_last, masks, Nc, avail, deterministic, seed, counter, counter_dev, actions, logp, values, stream);
+                                           critic_h_last, masks, Nc, avail, deterministic, seed, counter, counter_dev, actions, logp, values, nullptr,
+                                           stream);
   MAPPO_REQUIRE(actor_desc->in_dim <= 64 && critic_desc->in_dim <= 64, "recurrent_step_dual: both networks narrow (in_dim <= 64) or both wide (65..512)");
   MAPPO_REQUIRE(actor_desc->layer_N <= 1, "recurrent_step_dual: narrow inputs: layer_N <= 1 (two hidden layers do not fit the register file)");
   MAPPO_CLEAR_STICKY();
@@ -400,5 +411,66 @@ extern "C" int mappo_recurrent_step_dual(const float *actor_params, const mappo_
     default: if (relu) hipLaunchKernelGGL((gru_step3f_dual_kernel<1, 1>), grid, block, 0, st, a, c, g3); else hipLaunchKernelGGL((gru_step3f_dual_kernel<2, 1>), grid, block, 0, st, a, c, g3); break;
   }
   MAPPO_CHECK_LAUNCH("recurrent_step_dual");
+  return MAPPO_OK;
+}
+
+// The SMAC rollout step in ONE launch (smac_runner.py:110-151 across two consecutive steps): the insert of the env output of
+// step k - 1 into buffer slot k (mappo_insert_smac: masks / active_masks / bad_masks, rnn states x (1 - env done), slot copies) AND
+// get_actions / get_values of step k, which read that env output and the states the step before returned IN PLACE (the row mask is
+// derived from `dones` exactly as the insert derives masks[k]).  The insert was a launch of its own, 5 us of a 30-45 us step.
+extern "C" int mappo_recurrent_rollout_step(const float *actor_params, const mappo_net_desc *actor_desc, const float *critic_params,
+                                            const mappo_net_desc *critic_desc, const float *obs, const float *share_obs, const float *avail,
+                                            const float *rewards, int64_t rew_stride_n, int64_t rew_stride_m, const uint8_t *dones,
+                                            int64_t done_stride_n, int64_t done_stride_m, const uint8_t *bad_transition, const float *actor_h,
+                                            const float *critic_h, float *actor_h_next, float *critic_h_next, int32_t N, int32_t M,
+                                            int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
+                                            float *logp, float *values, const mappo_smac_slot *dst, mappo_stream_t stream) {
+  if (int rc = check_rec(actor_desc, "recurrent_rollout_step")) return rc;
+  if (int rc = check_rec(critic_desc, "recurrent_rollout_step")) return rc;
+  MAPPO_REQUIRE(critic_desc->out_dim == 1, "recurrent_rollout_step: critic out_dim must be 1");
+  MAPPO_REQUIRE(actor_params && critic_params && obs && share_obs && rewards && dones && actor_h && critic_h && actor_h_next && critic_h_next &&
+                    actions && logp && values && dst && N > 0 && M > 0, "recurrent_rollout_step: bad arguments");
+  MAPPO_REQUIRE(dst->obs && dst->share_obs && dst->rewards && dst->masks && dst->bad_masks && dst->active_masks && dst->rnn_states &&
+                    dst->rnn_states_critic && (!avail || dst->available_actions), "recurrent_rollout_step: incomplete destination slot");
+  MAPPO_REQUIRE(actor_desc->layer_N == critic_desc->layer_N && actor_desc->use_relu == critic_desc->use_relu,
+                "recurrent_rollout_step: the networks must share layer_N and the activation");
+  MAPPO_REQUIRE(((((uintptr_t)actor_h) | ((uintptr_t)critic_h) | ((uintptr_t)dst->rnn_states) | ((uintptr_t)dst->rnn_states_critic)) & 15) == 0,
+                "recurrent_rollout_step: state arrays must be 16-byte aligned");
+  const int Nc = N * M;
+  SmacInsert ins;
+  ins.obs = obs; ins.share = share_obs; ins.avail = avail; ins.rew = rewards; ins.rew_sn = rew_stride_n; ins.rew_sm = rew_stride_m;
+  ins.done = dones; ins.done_sn = done_stride_n; ins.done_sm = done_stride_m; ins.bad = bad_transition; ins.h_a = actor_h; ins.h_c = critic_h;
+  ins.obs_dst = dst->obs; ins.share_dst = dst->share_obs; ins.avail_dst = dst->available_actions; ins.rew_dst = dst->rewards;
+  ins.mask_dst = dst->masks; ins.bad_dst = dst->bad_masks; ins.active_dst = dst->active_masks; ins.ha_dst = dst->rnn_states;
+  ins.hc_dst = dst->rnn_states_critic; ins.N = N; ins.M = M; ins.D = actor_desc->in_dim; ins.S = critic_desc->in_dim;
+  ins.A = actor_desc->out_dim; ins.H = HID;
+  if (actor_desc->in_dim > 64 && critic_desc->in_dim > 64)
+    return mappo_recurrent_step_dual_wide_(actor_params, actor_desc, obs, actor_h, actor_h_next, critic_params, critic_desc, share_obs, critic_h,
+                                           critic_h_next, nullptr, Nc, avail, deterministic, seed, counter, counter_dev, actions, logp, values, &ins,
+                                           stream);
+  MAPPO_REQUIRE(actor_desc->in_dim <= 64 && critic_desc->in_dim <= 64 && actor_desc->layer_N <= 1,
+                "recurrent_rollout_step: both networks narrow (in_dim <= 64, layer_N <= 1) or both wide (65..512)");
+  MAPPO_CLEAR_STICKY();
+  GruFwdArgs a = {}, c = {};
+  a.params = actor_params; a.off = net_offsets(*actor_desc); a.x_rows = obs; a.desc = *actor_desc; a.h0 = actor_h; a.L = 1; a.Nc = Nc;
+  a.A = actor_desc->out_dim; a.head_mode = 2; a.h_last = actor_h_next; a.avail = avail; a.actions = actions; a.logp = logp;
+  a.deterministic = deterministic; a.seed = seed; a.counter = counter; a.counter_dev = counter_dev;
+  a.dones = dones; a.done_M = M; a.done_sn = done_stride_n; a.done_sm = done_stride_m;
+  c.params = critic_params; c.off = net_offsets(*critic_desc); c.x_rows = share_obs; c.desc = *critic_desc; c.h0 = critic_h; c.L = 1; c.Nc = Nc;
+  c.A = 1; c.head_mode = 1; c.h_last = critic_h_next; c.out = values;
+  c.dones = dones; c.done_M = M; c.done_sn = done_stride_n; c.done_sm = done_stride_m;
+  const int nt16 = (Nc + 15) / 16;
+  const int g3 = nt16 < NUM_CU ? nt16 : NUM_CU;
+  const int64_t most = (int64_t)Nc * (ins.D > ins.S ? ins.D : ins.S);
+  int nI = (int)((most + 2047) / 2048);                         // ~8 elements per thread
+  nI = nI < 1 ? 1 : (nI > 64 ? 64 : nI);
+  const dim3 grid(2 * g3 + nI), block(4 * WAVE);
+  hipStream_t st = as_stream(stream);
+  const bool relu = actor_desc->use_relu != 0;
+  switch (actor_desc->layer_N) {
+    case 0: if (relu) hipLaunchKernelGGL((gru_step3f_dual_ins_kernel<1, 0>), grid, block, 0, st, a, c, g3, ins, nI); else hipLaunchKernelGGL((gru_step3f_dual_ins_kernel<2, 0>), grid, block, 0, st, a, c, g3, ins, nI); break;
+    default: if (relu) hipLaunchKernelGGL((gru_step3f_dual_ins_kernel<1, 1>), grid, block, 0, st, a, c, g3, ins, nI); else hipLaunchKernelGGL((gru_step3f_dual_ins_kernel<2, 1>), grid, block, 0, st, a, c, g3, ins, nI); break;
+  }
+  MAPPO_CHECK_LAUNCH("recurrent_rollout_step");
   return MAPPO_OK;
 }

@@ -63,6 +63,12 @@ struct GruFwdArgs {
   // fused rollout step (gru_step3f_*): the trunk runs in the same launch on the rows x_rows [Nc][in_dim]
   const float *x_rows;
   mappo_net_desc desc;
+  // fused insert + step (mappo_recurrent_rollout_step): the row mask is derived from the env's `dones` of the step before
+  // (mask = 0 where ALL agents of the row's env report done, smac_runner.py:132-138) instead of read from the buffer slot the
+  // insert role of the same launch is writing
+  const uint8_t *dones;
+  int done_M;
+  int64_t done_sn, done_sm;
 };
 
 
@@ -145,7 +151,15 @@ __device__ __forceinline__ void gru_step3_tiles(const Step3W<TLN> &W, const GruF
     const bool ok = c < p.Nc;
     const int cc = ok ? c : 0;
     const int64_t hrow = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
-    const float mk = ok ? p.masks[p.rows ? (int64_t)p.rows[cc] : (int64_t)cc] : 0.f;
+    float mk;
+    if (p.dones) {
+      const int env = cc / p.done_M;
+      bool all = true;
+      for (int m = 0; m < p.done_M; ++m) all = all && p.dones[env * p.done_sn + m * p.done_sm] != 0;
+      mk = (ok && !all) ? 1.f : 0.f;
+    } else {
+      mk = ok ? p.masks[p.rows ? (int64_t)p.rows[cc] : (int64_t)cc] : 0.f;
+    }
     uint32_t dead = 0u;
     if (HM == 2 && p.avail && w == 0 && q == 0) dead = avail_dead_mask(p.avail + (int64_t)cc * A, A);    // the sampling lanes
     g4_t x[4], hm[4];

@@ -1312,6 +1312,7 @@ int wide16_launch_features_sk_dual(bool relu, int ln, dim3 grid, size_t lds_byte
                                    const Wide16Args &wc, const FwdArgs &c, int nA);
 // trunks + GRU step + heads of both networks in one launch (wide_recurrent_step_dual_kernel); one tile per workgroup
 struct WideStepIO {
+  const SmacInsert *ins;        // or NULL: no fused insert (then `masks` is read; with it the row mask comes from ins->done)
   const float *actor_h0, *critic_h0, *masks, *avail;
   float *actor_h_last, *critic_h_last, *actions, *logp, *values;
   int Nc, deterministic;
@@ -1465,7 +1466,15 @@ int wide16_launch_recurrent_step_dual(bool relu, int ln, size_t lds_bytes, hipSt
   ga.deterministic = io.deterministic; ga.seed = io.seed; ga.counter = io.counter; ga.counter_dev = io.counter_dev;
   gc.params = c.params; gc.off = c.off; gc.desc = c.desc; gc.h0 = io.critic_h0; gc.masks = io.masks; gc.L = 1; gc.Nc = io.Nc; gc.A = 1;
   gc.head_mode = 1; gc.h_last = io.critic_h_last; gc.out = io.values;
-  const dim3 grid((unsigned)(2 * nt16));
+  r.nI = 0;
+  if (io.ins) {
+    r.ins = *io.ins;
+    ga.dones = gc.dones = io.ins->done; ga.done_M = gc.done_M = io.ins->M; ga.done_sn = gc.done_sn = io.ins->done_sn; ga.done_sm = gc.done_sm = io.ins->done_sm;
+    const int64_t most = (int64_t)io.Nc * (io.ins->D > io.ins->S ? io.ins->D : io.ins->S);
+    const int64_t ni = (most + 2047) / 2048;                     // ~8 elements per thread
+    r.nI = (int)(ni < 1 ? 1 : (ni > 64 ? 64 : ni));
+  }
+  const dim3 grid((unsigned)(2 * nt16 + r.nI));
   if (ln == 0) return relu ? wide16_recurrent_step_one<true, 0>(grid, lds_bytes, st, r) : wide16_recurrent_step_one<false, 0>(grid, lds_bytes, st, r);
   if (ln == 1) return relu ? wide16_recurrent_step_one<true, 1>(grid, lds_bytes, st, r) : wide16_recurrent_step_one<false, 1>(grid, lds_bytes, st, r);
   return relu ? wide16_recurrent_step_one<true, 2>(grid, lds_bytes, st, r) : wide16_recurrent_step_one<false, 2>(grid, lds_bytes, st, r);
@@ -1780,7 +1789,7 @@ int mappo_recurrent_step_dual_wide_(const float *actor_params, const mappo_net_d
                                     float *actor_h_last, const float *critic_params, const mappo_net_desc *critic_desc, const float *share_obs,
                                     const float *critic_h0, float *critic_h_last, const float *masks, int32_t Nc, const float *avail,
                                     int32_t deterministic, uint64_t seed, uint64_t counter, const uint64_t *counter_dev, float *actions,
-                                    float *logp, float *values, mappo_stream_t stream) {
+                                    float *logp, float *values, const SmacInsert *ins, mappo_stream_t stream) {
   if (int rc = check_desc_trunk(actor_desc, "recurrent_step_dual")) return rc;
   if (int rc = check_desc_trunk(critic_desc, "recurrent_step_dual")) return rc;
   MAPPO_REQUIRE(actor_desc->in_dim > MAXD && critic_desc->in_dim > MAXD && actor_desc->in_dim <= 512 && critic_desc->in_dim <= 512,
@@ -1798,6 +1807,7 @@ int mappo_recurrent_step_dual_wide_(const float *actor_params, const mappo_net_d
   if (int rcp = wide_forward_prepare(a, wa, lba, ga, ba, sa, "recurrent_step_dual")) return rcp;
   if (int rcp = wide_forward_prepare(c, wc, lbc, gc, bc, sc, "recurrent_step_dual")) return rcp;
   WideStepIO io = {};
+  io.ins = ins;
   io.actor_h0 = actor_h0; io.critic_h0 = critic_h0; io.masks = masks; io.avail = avail; io.actor_h_last = actor_h_last;
   io.critic_h_last = critic_h_last; io.actions = actions; io.logp = logp; io.values = values; io.Nc = Nc; io.deterministic = deterministic;
   io.seed = seed; io.counter = counter; io.counter_dev = counter_dev;

@@ -686,6 +686,8 @@ __global__ __launch_bounds__(256, 1) void wide_features16_sk_dual_kernel(WideDua
 struct WideRecDualArgs {
   WideDualArgs d;
   GruFwdArgs ga, gc;
+  SmacInsert ins;             // nI > 0: workgroups [2 nA, 2 nA + nI) perform the SMAC insert of the env output the rows are read from
+  int nI;
 };
 template <bool RELU, int LN>
 __global__ __launch_bounds__(256, 1) void wide_recurrent_step_dual_kernel(WideRecDualArgs r) {
@@ -695,8 +697,9 @@ __global__ __launch_bounds__(256, 1) void wide_recurrent_step_dual_kernel(WideRe
   __shared__ float4 sX[4 * 64];
   const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const bool actor = (int)blockIdx.x < r.d.nA;                    // one tile per workgroup: grid = 2 x tiles
+  const bool actor = (int)blockIdx.x < r.d.nA;                    // one tile per workgroup: grid = 2 x tiles (+ insert workgroups)
   const int bid = actor ? (int)blockIdx.x : (int)blockIdx.x - r.d.nA, nb = r.d.nA;
+  if ((int)blockIdx.x >= 2 * r.d.nA) { insert_smac_body(r.ins, (int)blockIdx.x - 2 * r.d.nA, r.nI); return; }
   Step3W<0> W;
   if (actor) {
     gru_step3_load<3, 0>(W, r.ga, wv, n, q);

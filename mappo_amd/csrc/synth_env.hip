@@ -71,6 +71,68 @@ __global__ __launch_bounds__(256) void synth_smac_step_kernel(SynthArgs p) {
   }
 }
 
+// P consecutive steps in ONE launch (the runner's episode: like SyntheticMPEEnv, which draws an episode's block at its first step):
+// outputs are [P][...] pools the env hands out step by step as views, so that a rollout step has no env launch at all.  The state
+// part (agents die, envs terminate and restart) is sequential in the step: the thread that owns an agent's first element walks
+// the P steps for it; everything else is independent per (step, element).  Step p uses Philox counter ctr + p.
+__global__ __launch_bounds__(256) void synth_smac_pool_kernel(SynthArgs p, int P) {
+  const uint64_t ctr0 = *p.counter_dev;
+  const int W = p.D + p.S + p.A;
+  const int64_t NM = (int64_t)p.N * p.M, total = NM * W;
+  const uint64_t base_agent = (uint64_t)total, base_env = base_agent + (uint64_t)NM;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total * P; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t st = e / total, r = e - st * total;
+    const uint64_t ctr = ctr0 + (uint64_t)st;
+    const int64_t ag = r / W;
+    const int k = (int)(r - ag * W);
+    if (k < p.D) p.obs[(st * NM + ag) * p.D + k] = synth_normal(p.seed, ctr, (uint64_t)r);
+    else if (k < p.D + p.S) p.share[(st * NM + ag) * p.S + (k - p.D)] = synth_normal(p.seed, ctr, (uint64_t)r);
+    else {
+      const int a = k - p.D - p.S;
+      p.avail[(st * NM + ag) * p.A + a] = (a == 0 || synth_uniform(p.seed, ctr, 2 * (uint64_t)r) <= 0.7f) ? 1.f : 0.f;
+    }
+    if (k == 0 && st == 0) {                                     // this agent's state over the P steps
+      const int64_t env = ag / p.M;
+      bool dead = p.dead[ag] != 0;
+      for (int s2 = 0; s2 < P; ++s2) {
+        const uint64_t c2 = ctr0 + (uint64_t)s2;
+        const bool term = synth_uniform(p.seed, c2, 2 * (base_env + (uint64_t)env)) <= p.p_term;
+        dead = dead || synth_uniform(p.seed, c2, 2 * (base_agent + (uint64_t)ag)) <= p.p_death;
+        p.dones[(int64_t)s2 * NM + ag] = (dead || term) ? 1 : 0;
+        dead = dead && !term;
+        if (ag - env * p.M == 0) p.rewards[(int64_t)s2 * p.N + env] = synth_normal(p.seed, c2, base_env + (uint64_t)p.N + (uint64_t)env);
+      }
+      p.dead[ag] = dead ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long *tk = reinterpret_cast<unsigned long long *>(p.counter_dev);
+    const unsigned n_groups = gridDim.x < 32u ? gridDim.x : 32u, g = blockIdx.x % n_groups;
+    const unsigned in_group = (gridDim.x - g + n_groups - 1u) / n_groups;
+    if (atomicAdd(tk + 2 + g, 1ull) == (unsigned long long)in_group - 1ull) {
+      tk[2 + g] = 0ull;
+      if (atomicAdd(tk + 1, 1ull) == (unsigned long long)n_groups - 1ull) {
+        tk[1] = 0ull;
+        tk[0] = ctr0 + (unsigned long long)P;
+      }
+    }
+  }
+}
+
+extern "C" int mappo_synth_smac_pool(float *obs, float *share_obs, float *avail, float *rewards, uint8_t *dead, uint8_t *dones,
+                                     int32_t P, int32_t N, int32_t M, int32_t D, int32_t S, int32_t A, float p_death, float p_term,
+                                     uint64_t seed, uint64_t *counter_dev, mappo_stream_t stream) {
+  MAPPO_REQUIRE(obs && share_obs && avail && rewards && dead && dones && counter_dev, "synth_smac_pool: null argument");
+  MAPPO_REQUIRE(P > 0 && N > 0 && M > 0 && D > 0 && S > 0 && A > 0, "synth_smac_pool: bad shape");
+  SynthArgs p = {obs, share_obs, avail, rewards, dead, dones, counter_dev, N, M, D, S, A, p_death, p_term, seed};
+  const int64_t total = (int64_t)P * N * M * (D + S + A);
+  const int64_t blocks = (total + 255) / 256;
+  hipLaunchKernelGGL(synth_smac_pool_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, p, (int)P);
+  MAPPO_CHECK_LAUNCH("synth_smac_pool");
+  return MAPPO_OK;
+}
+
 extern "C" int mappo_synth_smac_step(float *obs, float *share_obs, float *avail, float *rewards, uint8_t *dead, uint8_t *dones,
                                      int32_t N, int32_t M, int32_t D, int32_t S, int32_t A, float p_death, float p_term,
                                      uint64_t seed, uint64_t *counter_dev, mappo_stream_t stream) {

@@ -57,7 +57,12 @@ class SyntheticSMACEnv:
     graph_safe = True
 
     def __init__(self, n_rollout_threads, num_agents=3, obs_dim=30, share_dim=48, n_actions=9, p_death=0.01, p_term=1.0 / 60,
-                 seed=1, device="cuda"):
+                 seed=1, device="cuda", pool_steps=0):
+        """pool_steps = P > 0: every P-th step() draws the next P steps in ONE launch (mappo_synth_smac_pool) and the steps hand out
+        views of that pool — like SyntheticMPEEnv's per-episode block (pass the episode length: a captured episode graph then
+        contains the pool launch of its first step).  0: one launch per step."""
+        self.pool_steps = int(pool_steps)
+        self._t = 0
         self.N, self.M, self.D, self.S, self.A = n_rollout_threads, num_agents, obs_dim, share_dim, n_actions
         self.p_death, self.p_term = p_death, p_term
         self.device = torch.device(device)
@@ -93,6 +98,21 @@ class SyntheticSMACEnv:
 
     def step(self, actions=None):
         N, M, dev = self.N, self.M, self.device
+        if dev.type == "cuda" and self.pool_steps > 0:
+            from mappo_amd import ops
+            P = self.pool_steps
+            if not hasattr(self, "_pool"):
+                self._pool = dict(obs=torch.empty(P, N, M, self.D, device=dev), share=torch.empty(P, N, M, self.S, device=dev),
+                                  avail=torch.empty(P, N, M, self.A, device=dev), rew=torch.empty(P, N, device=dev),
+                                  dones=torch.zeros(P, N, M, dtype=torch.bool, device=dev), bad=torch.zeros(N, M, dtype=torch.bool, device=dev),
+                                  ctr=torch.tensor([1] + [0] * 33, dtype=torch.int64, device=dev))
+            q = self._pool
+            i = self._t % P
+            if i == 0:
+                ops.synth_smac_pool(q["obs"], q["share"], q["avail"], q["rew"], self.dead, q["dones"], self.p_death, self.p_term,
+                                    self.seed, q["ctr"])
+            self._t += 1
+            return q["obs"][i], q["share"][i], q["rew"][i].view(N, 1, 1).expand(N, M, 1), q["dones"][i], q["bad"], q["avail"][i]
         if dev.type == "cuda":
             from mappo_amd import ops
             f = self._fused_state()

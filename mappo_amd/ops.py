@@ -92,6 +92,29 @@ def insert_smac(obs, share_obs, avail, rewards, dones, bad, rnn_states, rnn_stat
     _lib.check(rc, "mappo_insert_smac")
 
 
+def recurrent_rollout_step(actor_params, actor_desc, critic_params, critic_desc, obs, share_obs, avail, rewards, dones, bad, actor_h, critic_h,
+                           actor_h_next, critic_h_next, deterministic, seed, counter, counter_dev, actions, logp, values, slot):
+    """mappo_recurrent_rollout_step: SMAC insert of the pending env output (obs [N, M, D], share_obs [N, M, S], avail [N, M, A] or None,
+    rewards [N, M(, 1)], dones [N, M] bool, bad [N, M] bool or None; states [N*M, ., 64]) into the arrays of `slot` (dict: obs, share_obs,
+    available_actions, rewards, masks, bad_masks, active_masks, rnn_states, rnn_states_critic) + get_actions / get_values on it."""
+    N, M, _ = obs.shape
+    if rewards.dim() == 3:
+        rewards = rewards[..., 0]
+    sl = _lib.SmacSlot(*[(slot[k].data_ptr() if slot.get(k) is not None else None) for k, _ in _lib.SmacSlot._fields_])
+    for k, _ in _lib.SmacSlot._fields_:
+        t = slot.get(k)
+        if t is not None and not (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32):
+            raise ValueError(f"slot[{k}] must be a contiguous fp32 device tensor")
+    n = lambda t: _ptr(t, allow_none=True)
+    rc = _lib.load().mappo_recurrent_rollout_step(
+        _ptr(actor_params), C.byref(actor_desc), _ptr(critic_params), C.byref(critic_desc), _ptr(obs), _ptr(share_obs), n(avail),
+        C.c_void_p(rewards.data_ptr()), rewards.stride(0), rewards.stride(1), C.c_void_p(dones.data_ptr()), dones.stride(0), dones.stride(1),
+        C.c_void_p(bad.data_ptr()) if bad is not None else None, _ptr(actor_h), _ptr(critic_h), _ptr(actor_h_next), _ptr(critic_h_next),
+        int(N), int(M), int(bool(deterministic)), int(seed) & (2 ** 64 - 1), int(counter) & (2 ** 64 - 1),
+        _ptr(counter_dev, torch.int64, allow_none=True), _ptr(actions), _ptr(logp), _ptr(values), C.byref(sl), _stream())
+    _lib.check(rc, "mappo_recurrent_rollout_step")
+
+
 def recurrent_rows(perm, L, T, R, num_mini_batch):
     """perm [E, data_chunks] int64 (device) -> rows [E, nmb, L*mbs], h0_rows [E, nmb, mbs] int32 (mappo_recurrent_rows)."""
     E, chunks = perm.shape
@@ -509,6 +532,16 @@ def mpe_spread_step(agent_pos, agent_vel, landmark_pos, tstep, episode, actions,
                                            _ptr(dones, torch.uint8), int(N), int(M), int(L),
                                            int(episode_length), int(seed) & (2 ** 64 - 1), _stream())
     _lib.check(rc, "mappo_mpe_spread_step")
+
+
+def synth_smac_pool(obs, share_obs, avail, rewards, dead, dones, p_death, p_term, seed, counter):
+    """P steps of the synthetic SMAC-shaped env in one launch: pools obs [P, N, M, D], share_obs, avail, rewards [P, N], dones [P, N, M]."""
+    P, N, M, D = obs.shape
+    assert counter.numel() == 34
+    rc = _lib.load().mappo_synth_smac_pool(_ptr(obs), _ptr(share_obs), _ptr(avail), _ptr(rewards), _ptr(dead, torch.bool), _ptr(dones, torch.bool),
+                                           int(P), int(N), int(M), int(D), int(share_obs.shape[3]), int(avail.shape[3]), float(p_death),
+                                           float(p_term), int(seed), _ptr(counter, torch.int64), _stream())
+    _lib.check(rc, "mappo_synth_smac_pool")
 
 
 def synth_smac_step(obs, share_obs, avail, rewards, dead, dones, p_death, p_term, seed, counter):

@@ -19,8 +19,11 @@ class SMACRunner(Runner):
         self._rollout_graph = None          # None -> "warm" -> CUDAGraph
         # a device-resident env without data-dependent host control flow (mappo_amd.envs.synthetic) lets the whole episode
         # (T x collect / env.step / insert + compute) replay as one hipGraph, as in MPERunner.rollout
-        self._use_graph = (bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False))
-                           and config.get("dist_group") is None)
+        # (data-parallel runs, too: there is no collective inside the rollout; the capture uses thread-local error mode so that
+        # RCCL's watchdog thread stays legal, and falls back to eager launches if it fails — as MPERunner.rollout)
+        self._use_graph = bool(getattr(self.all_args, "use_hip_graph", True)) and bool(getattr(self.envs, "graph_safe", False))
+        self._dist_present = config.get("dist_group") is not None
+        self._fuse_insert = bool(getattr(self.all_args, "fuse_rollout_step", True))
 
     def run(self):
         self.warmup()
@@ -64,14 +67,40 @@ class SMACRunner(Runner):
 
     def _rollout_body(self):
         infos = None
-        self.trainer.policy.actor._counter_dev.add_(self.episode_length)   # fresh sampling stream per (replayed) episode
+        pol, b = self.trainer.policy, self.buffer
+        pol.actor._counter_dev.add_(self.episode_length)   # fresh sampling stream per (replayed) episode
+        # device envs + recurrent policies: the insert of step k - 1's env output rides in step k's launch (mappo_recurrent_rollout_step)
+        fuse = (self._fuse_insert and env_takes_device_actions(self.envs)
+                and pol.can_fuse_recurrent_step(b.n_rollout_threads * b.num_agents))
+        pending = None
         for step in range(self.episode_length):
-            values, actions, action_log_probs, rnn_states, rnn_states_critic = self.collect(step)
+            out = None
+            if pending is not None:
+                self.trainer.prep_rollout()
+                out = pol.collect_step_fused_recurrent(b, step, pending)
+                if out is None:                                 # not the layout the fused launch reads: plain insert, then collect
+                    self._insert_pending(pending)
+            if out is not None:
+                actions, rnn_states, rnn_states_critic = out
+                values, action_log_probs = b.value_preds[step], b.action_log_probs[step]
+            else:
+                values, actions, action_log_probs, rnn_states, rnn_states_critic = self.collect(step)
             obs, share_obs, rewards, dones, infos, available_actions = self.envs.step(actions)
-            self.insert((obs, share_obs, rewards, dones, infos, available_actions, values, actions, action_log_probs,
-                         rnn_states, rnn_states_critic))
+            if fuse and (infos is None or isinstance(infos, torch.Tensor)):
+                pending = (obs, share_obs if self.use_centralized_V else obs, rewards, dones, infos, available_actions, rnn_states,
+                           rnn_states_critic)
+            else:
+                pending = None
+                self.insert((obs, share_obs, rewards, dones, infos, available_actions, values, actions, action_log_probs,
+                             rnn_states, rnn_states_critic))
+        if pending is not None:
+            self._insert_pending(pending)                       # the last env output: slot T (read by compute())
         self.compute()
         return infos
+
+    def _insert_pending(self, pending):
+        obs, share_obs, rewards, dones, infos, available_actions, rnn_states, rnn_states_critic = pending
+        self.insert((obs, share_obs, rewards, dones, infos, available_actions, None, None, None, rnn_states, rnn_states_critic))
 
     def rollout(self):
         if not self._use_graph:
@@ -82,10 +111,20 @@ class SMACRunner(Runner):
             return infos
         if self._rollout_graph == "warm":
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._rollout_body()
-            self._rollout_graph = g
+            mode = dict(capture_error_mode="thread_local") if self._dist_present else {}
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, **mode):
+                    self._rollout_body()
+                self._rollout_graph = g
+            except Exception as e:
+                if not self._dist_present:
+                    raise
+                import warnings                              # never let a failed capture take a multi-GPU run down
+                warnings.warn(f"hipGraph capture of the rollout failed ({e}); launching eagerly")
+                torch.cuda.synchronize()
+                self._use_graph = False
+                return self._rollout_body()
         self._rollout_graph.replay()
         return None
 

@@ -30,7 +30,7 @@ def make_runner(name):
     torch.manual_seed(1)
     dev = torch.device("cuda:0")
     if kind == "smac":
-        env = SyntheticSMACEnv(N, M, D, S, A, seed=1, device=dev); R = SMACRunner
+        env = SyntheticSMACEnv(N, M, D, S, A, seed=1, device=dev, pool_steps=T); R = SMACRunner
     else:
         env = SyntheticMPEEnv(N, M, D, A, T, seed=1, device=dev); R = MPERunner
         if kind == "mpe5":

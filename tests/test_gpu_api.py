@@ -355,3 +355,19 @@ def test_synthetic_smac_env_fused_step():
     for _ in range(20):
         o2 = env2.step(None)[0]
     assert torch.equal(o2, obs)
+
+
+@pytest.mark.gpu
+def test_synthetic_smac_env_pooled_equals_stepwise():
+    """pool_steps = P (P steps per launch, handed out as views) produces exactly the stream of the one-launch-per-step env:
+    observations, availability, rewards, dones and the carried `dead` state, over more than two pools."""
+    from mappo_amd.envs.synthetic import SyntheticSMACEnv
+    kw = dict(num_agents=4, obs_dim=30, share_dim=48, n_actions=9, p_death=0.05, p_term=0.1, seed=5)
+    a, b = SyntheticSMACEnv(37, **kw), SyntheticSMACEnv(37, pool_steps=7, **kw)
+    a.reset(); b.reset()
+    for t in range(17):
+        xa, xb = a.step(None), b.step(None)
+        for i, (u, v) in enumerate(zip(xa, xb)):
+            assert torch.equal(u, v), (t, i)
+        if (t + 1) % 7 == 0:
+            assert torch.equal(a.dead, b.dead), t          # (inside a pool the pooled env's state already sits at the pool's end)

@@ -668,3 +668,60 @@ def test_config4_per_gpu_size_train_vs_oracle_on_active_subset(M):
     for net, onet in ((pol.actor, opol.actor), (pol.critic, opol.critic)):
         for k, v in net.state_dict().items():
             close(v, onet.state_dict()[k].numpy(), 2e-4, 1e-5, k)
+
+
+@pytest.mark.parametrize("Do,Ds,A,N,Ma", [(30, 48, 9, 37, 3), (176, 322, 18, 9, 10)])
+def test_fused_insert_and_recurrent_step_matches_separate_launches(M, Do, Ds, A, N, Ma):
+    """mappo_recurrent_rollout_step (SMAC insert of the pending env output + get_actions / get_values on it, one launch) ==
+    SharedReplayBuffer.insert_smac_fused followed by the rollout step on the slot it filled (smac_runner.py:110-151): the slot
+    arrays bit for bit (obs, share_obs, available_actions, rewards, masks, bad_masks, active_masks, masked rnn states), the same
+    actions, log-probs / values / next states to fp32 rounding.  Narrow (trunks in registers) and wide (split-K trunks) inputs."""
+    from mappo_amd import recurrent
+    T = 6
+    a = make_args(M, episode_length=T, n_rollout_threads=N, use_recurrent_policy=True, algorithm_name="rmappo")
+    torch.manual_seed(5)
+    pol = M.R_MAPPOPolicy(a, [Do], [Ds], M.Discrete(A))
+    R = N * Ma
+    assert pol.can_fuse_recurrent_step(R)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    obs, share = rnd(N, Ma, Do), rnd(N, Ma, Ds)
+    avail = (torch.rand(N, Ma, A, device="cuda", generator=g) < 0.7).float()
+    avail[:, :, 0] = 1.0
+    rew = rnd(N).view(N, 1, 1).expand(N, Ma, 1)
+    dones = torch.rand(N, Ma, device="cuda", generator=g) < 0.4
+    dones[::3] = True                                              # some envs with ALL agents done: masks 0, states reset
+    bad = torch.rand(N, Ma, device="cuda", generator=g) < 0.2
+    ha, hc = rnd(R, 1, 64), rnd(R, 1, 64)
+    step = 3
+    names = ("obs", "share_obs", "available_actions", "rewards", "masks", "bad_masks", "active_masks", "rnn_states", "rnn_states_critic",
+             "actions", "action_log_probs", "value_preds")
+    res = []
+    for fused in (False, True):
+        buf = M.SharedReplayBuffer(a, Ma, [Do], [Ds], M.Discrete(A))
+        for nme in names:
+            getattr(buf, nme).fill_(float("nan"))
+        buf.step = step - 1
+        if fused:
+            out = pol.collect_step_fused_recurrent(buf, step, (obs, share, rew, dones, bad, avail, ha, hc))
+            assert out is not None
+            _, na, nc = out
+        else:
+            assert buf.insert_smac_fused(share, obs, rew, dones, bad, avail, ha, hc)
+            _, na, nc = pol.collect_into(buf, step, use_available_actions=True)
+        assert buf.step == step
+        res.append(dict({nme: getattr(buf, nme).clone() for nme in names}, na=na.clone(), nc=nc.clone()))
+    sep, fus = res
+    for nme in names[:9]:
+        lo = step - 1 if nme == "rewards" else step
+        np.testing.assert_array_equal(fus[nme][lo].cpu().numpy(), sep[nme][lo].cpu().numpy(), err_msg=nme)
+        other = torch.ones(fus[nme].shape[0], dtype=torch.bool)
+        other[lo] = False
+        assert torch.isnan(fus[nme][other]).all(), nme             # nothing but the slot was written
+    np.testing.assert_array_equal(fus["actions"][step].cpu().numpy(), sep["actions"][step].cpu().numpy())
+    for nme in ("action_log_probs", "value_preds"):
+        np.testing.assert_allclose(fus[nme][step].cpu().numpy(), sep[nme][step].cpu().numpy(), rtol=2e-6, atol=2e-6, err_msg=nme)
+    np.testing.assert_allclose(fus["na"].cpu().numpy(), sep["na"].cpu().numpy(), rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(fus["nc"].cpu().numpy(), sep["nc"].cpu().numpy(), rtol=2e-6, atol=2e-6)
+    picked = torch.gather(avail.view(R, A), 1, fus["actions"][step].view(R, 1).long())
+    assert float(picked.min()) == 1.0
