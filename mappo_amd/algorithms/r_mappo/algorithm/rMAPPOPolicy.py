@@ -4,6 +4,8 @@ Owns ONE flat HBM buffer `[actor params | critic params]` (each padded to 256 fl
 step counters and hyper-parameters on the device; `actor` / `critic` are nn.Module shells viewing it (same
 state_dict keys as the reference), `actor_optimizer` / `critic_optimizer` are facades over the fused
 clip+Adam kernel (mappo_clip_adam) that keep `param_groups[..]['lr']`, `state_dict()` and `zero_grad()`."""
+import os
+
 import torch
 
 from mappo_amd import flat as flat_layout
@@ -199,7 +201,9 @@ class R_MAPPOPolicy:
         a, c = self.actor.desc, self.critic.desc
         if max(a.in_dim, c.in_dim) <= 64:
             return a.layer_N <= 1 and n_rows <= 1024
-        return min(a.in_dim, c.in_dim) > 64 and n_rows <= 16 * 1024
+        # wide inputs: one 16-row tile per workgroup, every workgroup fetching its own copy of the weights — beyond ~1 tile per CU and network (measured crossover between 2 560 and 5 120 rows at the MMM2 shape)
+        # the separate launches (8 tiles per workgroup share a weight stream) are faster
+        return min(a.in_dim, c.in_dim) > 64 and n_rows <= int(os.environ.get("MAPPO_WIDE_FUSED_MAX_ROWS", 4096))
 
     @torch.no_grad()
     def collect_step_fused_recurrent(self, buffer, step, pending, deterministic=False):

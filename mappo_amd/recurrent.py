@@ -101,7 +101,7 @@ def step_dual(actor, critic, obs, cent_obs, rnn_a, rnn_c, masks, avail, determin
     ha = torch.empty(Nc, 1, H, dtype=torch.float32, device=dev)
     hc = torch.empty(Nc, 1, H, dtype=torch.float32, device=dev)
     wide = min(actor.desc.in_dim, critic.desc.in_dim) > 64
-    if (((max(actor.desc.in_dim, critic.desc.in_dim) <= 64 and actor.desc.layer_N <= 1 and Nc <= 1024) or (wide and Nc <= 16 * 1024))
+    if (((max(actor.desc.in_dim, critic.desc.in_dim) <= 64 and actor.desc.layer_N <= 1 and Nc <= 1024) or (wide and Nc <= 4096))
             and os.environ.get("MAPPO_FUSED_STEP", "1") != "0"):
         # wide inputs: split-K trunks + GRU step + heads of both networks in one launch, one 16-row tile per 4-wave workgroup
         # narrow inputs, at most 64 tiles per network: trunks, GRU steps and heads of both networks in ONE launch (every wave
