@@ -276,6 +276,10 @@ __device__ __forceinline__ void categorical_act_lane(float *zl, int A, const flo
   categorical_act_mask(zl, A, av ? avail_dead_mask(av, A) : 0u, deterministic, seed, ctr, index, action, logp);
 }
 
+// exp / log here run on the hardware transcendental units (v_exp_f32 / v_log_f32, 1 ulp): this epilogue is the serial tail of every
+// rollout step (one lane per row walks the actions), and the libm forms are ~20-25 instructions per call, 2 A + 1 of them
+__device__ __forceinline__ float hw_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896341f * x); }
+__device__ __forceinline__ float hw_log(float x) { return 0.693147180559945309f * __builtin_amdgcn_logf(x); }
 __device__ __forceinline__ void categorical_act_mask(float *zl, int A, uint32_t dead, bool deterministic, uint64_t seed,
                                                      uint64_t ctr, uint64_t index, float &action, float &logp) {
   float zmax = -FLT_MAX;
@@ -285,8 +289,8 @@ __device__ __forceinline__ void categorical_act_mask(float *zl, int A, uint32_t 
     zmax = fmaxf(zmax, za);
   }
   float se = 0.f;
-  for (int a = 0; a < A; ++a) se += expf(zl[a] - zmax);
-  const float lse = zmax + logf(se);
+  for (int a = 0; a < A; ++a) se += hw_exp(zl[a] - zmax);
+  const float lse = zmax + hw_log(se);
   int chosen = 0;
   if (deterministic) {
     float best = -FLT_MAX;                         // probs.argmax: first maximum
@@ -296,7 +300,7 @@ __device__ __forceinline__ void categorical_act_mask(float *zl, int A, uint32_t 
     float c = 0.f;
     bool found = false;
     for (int a = 0; a < A; ++a) {
-      const float pa = expf(zl[a] - lse);
+      const float pa = hw_exp(zl[a] - lse);
       c += pa;
       if (!found && pa > 0.f) chosen = a;        // fallback: last action with support
       if (!found && u < c) { chosen = a; found = true; }

@@ -322,6 +322,12 @@ __device__ __forceinline__ void prefetch16x(Prefetch16<true> &pf, const UpdArgs 
   }
 }
 
+// exp / log on the hardware transcendental units (v_exp_f32 / v_log_f32, 1 ulp, as the GRU gate nonlinearities): the libm forms are
+// ~20 / ~25 instructions each on a pipe the MFMAs share, five per lane and tile in the actor's loss.  Arguments here are
+// z - zmax <= 0 (exp underflows to exactly 0 for masked logits, as libm's), se in [1, A], and a log-ratio of O(1).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896341f * x); }
+__device__ __forceinline__ float fast_log(float x) { return 0.693147180559945309f * __builtin_amdgcn_logf(x); }
+
 // Actor objective of one sample in the head layout: lane (n, q) holds z[i] = logit of action 4 i + q (A <= 16).  On return z
 // holds d(actor objective) / d logits.  Same expressions as actor_loss_regs (mlp_core.h); the sums over actions run over
 // the lane's registers first and the 4 lanes of the sample second.
@@ -339,9 +345,9 @@ __device__ __forceinline__ void actor_loss_quad(f32x4 &z, int A, int q, uint32_t
   const float zmax = quad_max16(zm);
   float e[4], se = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { e[i] = valid[i] ? expf(z[i] - zmax) : 0.f; se += e[i]; }
+  for (int i = 0; i < 4; ++i) { e[i] = valid[i] ? fast_exp(z[i] - zmax) : 0.f; se += e[i]; }
   se = quad_sum16(se);
-  const float log_se = logf(se), inv_se = 1.0f / se;
+  const float log_se = fast_log(se), inv_se = __builtin_amdgcn_rcpf(se);
   float hp = 0.f, za = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -352,7 +358,7 @@ __device__ __forceinline__ void actor_loss_quad(f32x4 &z, int A, int q, uint32_t
   const float H = -quad_sum16(hp);
   const float z_act = quad_sum16(za);                     // one lane / register of the sample is non-zero: exact
   const float logp = (z_act - zmax) - log_se;
-  const float ratio = expf(logp - old_lp);
+  const float ratio = fast_exp(logp - old_lp);
   const float s1 = ratio * adv, s2 = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * adv;
   const float w = cfg.use_policy_active_masks ? active : 1.f;
   const float dlogp = (s1 <= s2) ? -(w * scale_pi) * adv * ratio : 0.f;
