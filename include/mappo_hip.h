@@ -321,8 +321,8 @@ int mappo_trunk_backward(const float *params, const mappo_net_desc *desc /*host*
 
 /* ---- K9, training pass on 16-sequence tiles (gru_train16.hip; rnn.py:25-79 inside r_mappo.py:91-164) -------------------------
  * One PPO update of a recurrent network on Nc sequences of L steps (time-major minibatch, column t*Nc + c) is
- *   mappo_mlp_features_seq   trunk features, tiled per (t, 16 sequences), BLOCKED per tile (in_dim <= 64; wider inputs: mappo_mlp_features,
- *                            feature-major, with x_blocked = 0 below)
+ *   mappo_mlp_features_seq   trunk features, tiled per (t, 16 sequences), BLOCKED per tile (in_dim <= 64 with layer_N <= 1, or in_dim 65..512
+ *                            with Nc % 16 == 0; otherwise mappo_mlp_features, feature-major, with x_blocked = 0 below)
  *   mappo_gru16_forward_loss gi = W_ih x AND gh = W_hh (h mask) in one accumulator set, gates, h_t, then rnn.norm -> head -> PPO /
  *                            value loss -> their backward in the same registers: stores {h mask, r, z, n, W_hn h + b_hn, d h_t} per
  *                            step (gi and h_t never reach HBM), head + rnn.norm gradient columns of one slab row per workgroup,
@@ -330,7 +330,8 @@ int mappo_trunk_backward(const float *params, const mappo_net_desc *desc /*host*
  *   mappo_gru16_backward     reverse time: d gates (in place over r, z, n, gh_n), carry = (W_hh^T d gh + d h z) mask, and
  *                            d x_t = W_ih^T d gi from the same registers (blocked over the d h component, or feature-major dxT)
  *   mappo_gru16_wgrad        dW_ih, dW_hh, db_ih, db_hh = sum over rows (d gates)^T (x | h mask) -> slab rows
- *   mappo_trunk_backward_seq backward of the trunk from the blocked d x (in_dim <= 64; wider: mappo_trunk_backward with dxT)
+ *   mappo_trunk_backward_seq backward of the trunk from the blocked d x (same shapes as mappo_mlp_features_seq; otherwise
+ *                            mappo_trunk_backward with dxT)
  * scratch: mappo_gru16_scratch_floats(L, Nc) floats, [6][L][ceil(Nc/16)][4][64 lanes][4]: component c, step t, tile j, feature
  * block b; lane (n, q) holds features 16 b + 4 q + 0..3 of sequence 16 j + n (one contiguous KiB per wave access).  A blocked
  * feature array (x, d x) is one such component: mappo_gru16_blocked_floats(L, Nc).  mappo_gru16_slabs: slab rows written. */
@@ -352,6 +353,8 @@ int mappo_gru16_wgrad(const mappo_net_desc *desc /*host*/, const float *x, int32
                       float *slabs, int64_t slab_stride, int64_t slab_col0, mappo_stream_t stream);
 int mappo_trunk_backward_seq(const float *params, const mappo_net_desc *desc /*host*/, const float *x, const int32_t *rows, int32_t L,
                              int32_t Nc, const float *dx_blocked, float *slabs, int64_t slab_stride, int64_t slab_col0,
+                             float *wide_ws /*in_dim > 64 (then Nc % 16 == 0): mappo_wide_workspace_floats(L*Nc) floats, followed by
+                                              mappo_wide_l1_backward with the layout of MAPPO_PRODUCER_TRUNK_BACKWARD; else NULL*/,
                              mappo_stream_t stream);
 
 /* ---- K10/K11: slab reduction, global-norm clip, Adam (r_mappo.py:143-148,157-162; torch Adam) -------

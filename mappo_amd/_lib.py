@@ -89,7 +89,7 @@ SIGNATURES = {
                                  [C.POINTER(PpoCfg), _P, _P, _I64, _I64, _P, _P]),
     "mappo_gru16_backward": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _P]),
     "mappo_gru16_wgrad": (C.c_int, [C.POINTER(NetDesc), _P, _I32, _P, _I32, _I32, _P, _I64, _I64, _P]),
-    "mappo_trunk_backward_seq": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _I64, _I64, _P]),
+    "mappo_trunk_backward_seq": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _I32, _I32, _P, _P, _I64, _I64, _P, _P]),
     "mappo_recurrent_rollout_step": (C.c_int, [_P, C.POINTER(NetDesc), _P, C.POINTER(NetDesc), _P, _P, _P, _P, _I64, _I64, _P, _I64, _I64, _P,
                                                _P, _P, _P, _P, _I32, _I32, _I32, _U64, _U64, _P, _P, _P, _P, C.POINTER(SmacSlot), _P]),
     "mappo_mlp_features_dual": (C.c_int, [_P, C.POINTER(NetDesc), _P, _P, _P, C.POINTER(NetDesc), _P, _P, _I64, _P]),

@@ -880,6 +880,8 @@ extern "C" int32_t mappo_gru16_slabs(int32_t L, int32_t Nc) {
   return a > b ? a : b;
 }
 
+int mlp_features_blocked_wide_(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows, int64_t B,
+                               float *out_blocked, mappo_stream_t stream);      // mlp.hip
 template <bool RELU, int LN>
 static int feat16_launch(const Feat16Args &a, dim3 grid, dim3 block, hipStream_t st) {
   hipLaunchKernelGGL((gru16_features_kernel<RELU, LN>), grid, block, (size_t)T16Lds<LN>::TOTAL * sizeof(float), st, a);
@@ -890,8 +892,10 @@ extern "C" int mappo_mlp_features_seq(const float *params, const mappo_net_desc 
                                       int32_t L, int32_t Nc, float *out_blocked, mappo_stream_t stream) {
   MAPPO_REQUIRE(desc && desc->hidden == HID, "mlp_features_seq: hidden_size unsupported");
   MAPPO_REQUIRE(params && x && out_blocked && L > 0 && Nc > 0, "mlp_features_seq: bad arguments");
-  MAPPO_REQUIRE(desc->in_dim >= 1 && desc->in_dim <= MAXD && desc->layer_N >= 0 && desc->layer_N <= 1,
-                "mlp_features_seq: in_dim %d / layer_N %d take mappo_mlp_features (feature-major)", desc->in_dim, desc->layer_N);
+  if (desc->in_dim > MAXD)       // wide inputs (Nc % 16 == 0): the one-launch wide forward writes the same blocked form (mlp.hip)
+    return mlp_features_blocked_wide_(params, desc, x, rows, (int64_t)L * Nc, out_blocked, stream);
+  MAPPO_REQUIRE(desc->in_dim >= 1 && desc->layer_N >= 0 && desc->layer_N <= 1,
+                "mlp_features_seq: layer_N %d takes mappo_mlp_features (feature-major)", desc->layer_N);
   MAPPO_CLEAR_STICKY();
   Feat16Args a = {};
   a.params = params; a.off = net_offsets(*desc); a.x = x; a.rows = rows; a.L = L; a.Nc = Nc; a.D = desc->in_dim;

@@ -80,7 +80,11 @@ __device__ __forceinline__ void forward16_tail(const FwdArgs &p, float *lds, con
 #pragma unroll
     for (int b = 0; b < 4; ++b) xs[b * 64 + q * 16 + j] = make_float4(h[b][0], h[b][1], h[b][2], h[b][3]);
   } else if (MODE == 2) {
-    if (ok) {
+    if (p.out_blocked) {                                            // one contiguous KiB per store instruction (B % 16 == 0)
+      float *ob = p.out + ((i >> 4) * 4) * 256 + (q * 16 + j) * 4;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) *reinterpret_cast<float4 *>(ob + b * 256) = make_float4(h[b][0], h[b][1], h[b][2], h[b][3]);
+    } else if (ok) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll

@@ -596,6 +596,9 @@ struct FwdArgs {
   // env's output read in place (fused rollout step); x_M == 0: contiguous rows x[i * in_dim]
   int64_t x_sn, x_sm;
   int x_M;
+  // MODE 2 through forward16_tail (wide inputs) only: write the trunk output BLOCKED per 16-row tile, out[((i >> 4) * 4 + b) * 256 +
+  // 4 * lane + r] = feature 16 b + 4 q + r of row i (B a multiple of 16) — the layout of the recurrent training kernels (gru_train16.hip)
+  int out_blocked;
 };
 
 // XW: 0 = in_dim <= 32, 1 = in_dim <= 64 (rows prefetched into registers), 2 = in_dim > 64 (K-chunked layer 1)
@@ -764,7 +767,7 @@ struct UpdArgs {
   int red_base;              // start of that range (b1 for wide inputs: W1 / feature-norm grads come from wide_l1_bwd_kernel)
   float *wide_ws;            // wide inputs: [64][B] dz1 (feature-major) | mean0[B] | rstd0[B]
   const float *dHT;          // HEAD 3: gradient w.r.t. the trunk output, feature-major [64][B]
-  int seq_nc;                // HEAD 3, in_dim <= 64: > 0 = the B rows are a time-major [L][seq_nc] minibatch tiled per (t, 16 sequences) and dHT is BLOCKED per tile (gru_train16.hip)
+  int seq_nc;                // HEAD 3 (wide inputs: seq_nc a multiple of 16, so the tiles of the flat order ARE the sequence tiles): > 0 = the B rows are a time-major [L][seq_nc] minibatch tiled per (t, 16 sequences) and dHT is BLOCKED per tile (gru_train16.hip)
   // HEAD 0
   const float *dout;
   // HEAD 1 / 2 (buffer-order arrays, indexed by rows)
@@ -2000,6 +2003,16 @@ extern "C" int mappo_mlp_features(const float *params, const mappo_net_desc *des
   return launch_forward<2>(a, as_stream(stream), "mlp_features");
 }
 
+// wide-input branch of mappo_mlp_features_seq (gru_train16.hip): the one-launch wide forward with the blocked output form
+int mlp_features_blocked_wide_(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows, int64_t B,
+                               float *out_blocked, mappo_stream_t stream) {
+  if (int rc = check_desc_trunk(desc, "mlp_features_seq")) return rc;
+  MAPPO_REQUIRE(desc->in_dim > MAXD && desc->in_dim <= 512 && (B & 15) == 0, "mlp_features_seq: wide inputs need in_dim <= 512 and Nc %% 16 == 0");
+  FwdArgs a = {};
+  a.params = params; a.x = x; a.rows = rows; a.out = out_blocked; a.desc = *desc; a.B = B; a.out_blocked = 1;
+  return launch_forward<2>(a, as_stream(stream), "mlp_features_seq");
+}
+
 extern "C" int mappo_actor_act(const float *params, const mappo_net_desc *desc, const float *obs, const float *avail,
                                int64_t B, int32_t deterministic, uint64_t seed, uint64_t counter,
                                const uint64_t *counter_dev, float *actions, float *logp, mappo_stream_t stream) {
@@ -2230,13 +2243,14 @@ extern "C" int mappo_trunk_backward(const float *params, const mappo_net_desc *d
 // tile (the d x component gru16_bwd_kernel leaves in its scratch); in_dim <= 64
 extern "C" int mappo_trunk_backward_seq(const float *params, const mappo_net_desc *desc, const float *x, const int32_t *rows,
                                         int32_t L, int32_t Nc, const float *dx_blocked, float *slabs, int64_t slab_stride,
-                                        int64_t slab_col0, mappo_stream_t stream) {
+                                        int64_t slab_col0, float *wide_ws, mappo_stream_t stream) {
   if (int rc = check_desc_trunk(desc, "trunk_backward_seq")) return rc;
   MAPPO_REQUIRE(params && x && dx_blocked && slabs && L > 0 && Nc > 0, "trunk_backward_seq: bad arguments");
-  MAPPO_REQUIRE(desc->in_dim <= MAXD && desc->layer_N <= 1, "trunk_backward_seq: in_dim %d / layer_N %d take mappo_trunk_backward", desc->in_dim, desc->layer_N);
+  MAPPO_REQUIRE(desc->in_dim <= 512 && desc->layer_N <= 1, "trunk_backward_seq: in_dim %d / layer_N %d take mappo_trunk_backward", desc->in_dim, desc->layer_N);
+  MAPPO_REQUIRE(desc->in_dim <= MAXD || (Nc & 15) == 0, "trunk_backward_seq: wide inputs need Nc %% 16 == 0 (Nc = %d)", Nc);
   UpdArgs a = {};
   a.params = params; a.x = x; a.rows = rows; a.dHT = dx_blocked; a.slabs = slabs; a.slab_stride = slab_stride;
-  a.slab_col0 = slab_col0; a.desc = *desc; a.B = (int64_t)L * Nc; a.seq_nc = Nc;
+  a.slab_col0 = slab_col0; a.desc = *desc; a.B = (int64_t)L * Nc; a.seq_nc = Nc; a.wide_ws = wide_ws;
   return launch_update<3>(a, as_stream(stream), "trunk_backward_seq");
 }
 

@@ -438,7 +438,9 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
   const int D = p.desc.in_dim, A = p.desc.out_dim, C = (D + 3) >> 2;
   const bool fnorm = p.desc.use_feature_norm != 0;
   const float inv_D = 1.0f / (float)D;
-  const bool seq = HEAD == 3 && !XL1 && p.seq_nc > 0;       // sequence tiling + blocked d(trunk output) (recurrent training, gru_train16.hip)
+  // sequence tiling + blocked d(trunk output) (recurrent training, gru_train16.hip); wide inputs (XL1) are only given multiples of
+  // 16 sequences, for which the flat 16-row tiles already are the sequence tiles
+  const bool seq = HEAD == 3 && p.seq_nc > 0;
   const int64_t n_tiles = seq ? (p.B / p.seq_nc) * ((p.seq_nc + 15) >> 4) : (p.B + 15) / 16;
   const int64_t tile_stride = (int64_t)nb * n_waves;
   const int64_t tile0 = (int64_t)wave * nb + bid;          // remainder of the last round spreads over all CUs

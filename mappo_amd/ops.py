@@ -461,9 +461,12 @@ def gru16_wgrad(desc, x, x_blocked, scratch, L, Nc, slabs, slab_stride, slab_col
 
 
 def trunk_backward_seq(params, desc, x, rows, L, Nc, dx_blocked, slabs, slab_stride, slab_col0):
+    ws = wide_workspace(desc, L * Nc, x.device)
     rc = _lib.load().mappo_trunk_backward_seq(_ptr(params), C.byref(desc), _ptr(x), _ptr(rows, torch.int32, allow_none=True), int(L), int(Nc),
-                                              _ptr(dx_blocked), _ptr(slabs), int(slab_stride), int(slab_col0), _stream())
+                                              _ptr(dx_blocked), _ptr(slabs), int(slab_stride), int(slab_col0), _ptr(ws, allow_none=True),
+                                              _stream())
     _lib.check(rc, "mappo_trunk_backward_seq")
+    _wide(desc, x, rows, L * Nc, slabs, slab_stride, slab_col0, params, ws, PRODUCER_TRUNK_BACKWARD)
 
 
 # ---- K10 / K11 ------------------------------------------------------------------------------------

@@ -55,6 +55,7 @@ class _Scratch:
 
 
 _scratch = _Scratch()
+_WIDE_BLOCKED = os.environ.get("MAPPO_WIDE_BLOCKED", "1") != "0"             # A/B switch
 _TWO_STREAMS = os.environ.get("MAPPO_REC_TWO_STREAMS", "1") != "0"   # the two networks' chains on two streams (A/B: one after the other)
 
 
@@ -182,7 +183,9 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
     nets.append((pol.critic, src["share_obs"], src["h0_c"], 2, pc, pol.seg_bounds[1], "critic"))
 
     def one_net(net, x, h0, head, part, col0, tag):          # 16-sequence-tile kernels (gru_train16.hip)
-        narrow = net.desc.in_dim <= 64 and net.desc.layer_N <= 1
+        # blocked trunk features / d x (one contiguous KiB per wave access): narrow inputs always, wide ones when the sequence count
+        # is a multiple of 16 (the flat 16-row tiles of the wide kernels then are the (t, 16 sequences) tiles)
+        narrow = net.desc.layer_N <= 1 and (net.desc.in_dim <= 64 or (net.desc.in_dim <= 512 and Nc % 16 == 0 and _WIDE_BLOCKED))
         s = _scratch.get16(dev, L, Nc, tag, narrow)
         if narrow:
             ops.mlp_features_seq(net.flat, net.desc, x, rows, L, Nc, s["feat"])
