@@ -201,6 +201,221 @@ struct F16Lds {
   static_assert(G16_WAVES * NBH * 4 * 256 <= 2 * G16_NG * HID, "epilogue overlays the GRU weights");
 };
 
+
+// ---- the per-row tail: rnn.norm, head, loss and back to d h_t --------------------------------------------------------------------
+// Shared by gru16_fwd_kernel (inside its time loop) and gru16_head_kernel (the small-batch pass over all (t, tile) row tiles).
+template <int HEAD, int NBH>
+struct Tail16Acc {                                                // one wave's running sums
+  f32x4 gWh[HEAD == 1 ? NBH : 1][HEAD == 1 ? 4 : 1];
+  float gBh[HEAD == 1 ? NBH : 1];
+  float gWc, gNw, gNb;                                            // critic head product / rnn.norm gradients: lane = feature
+  float lacc[3];
+  __device__ __forceinline__ void clear() {
+    gWc = gNw = gNb = 0.f;
+    lacc[0] = lacc[1] = lacc[2] = 0.f;
+#pragma unroll
+    for (int bo = 0; bo < (HEAD == 1 ? NBH : 1); ++bo) {
+      gBh[bo] = 0.f;
+#pragma unroll
+      for (int bk = 0; bk < (HEAD == 1 ? 4 : 1); ++bk) gWh[bo][bk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+};
+struct Tail16In { float f0, f1, f2, f3; uint32_t dead; };         // a row's loss inputs (requested early, used late)
+struct Tail16Lds { const float *rn_g, *rn_b, *wh, *bh; float *Uy, *Udl; };
+
+template <int HEAD, int NBH>
+__device__ __forceinline__ Tail16In tail16_load(const Gru16Args &p, int64_t brow, int q, int A) {
+  Tail16In r;
+  r.f3 = 0.f; r.dead = 0u;
+  if constexpr (HEAD == 1) {
+    r.f0 = p.actions[brow]; r.f1 = p.old_logp[brow]; r.f2 = p.adv[brow]; r.f3 = p.active[brow];
+    if (p.avail) {
+      const float *av = p.avail + brow * A;
+      float v[NBH][4];
+#pragma unroll
+      for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[bo][i] = av[min(16 * bo + 4 * q + i, A - 1)];
+#pragma unroll
+      for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r.dead |= ((16 * bo + 4 * q + i < A && v[bo][i] == 0.f) ? 1u : 0u) << (4 * bo + i);
+    }
+  } else {
+    r.f0 = p.v_old[brow]; r.f1 = p.returns[brow]; r.f2 = p.active[brow];
+  }
+  return r;
+}
+
+// h: the wave's tile of h_t (accumulator layout); d <- d h_t without the recurrent term
+template <int HEAD, int NBH>
+__device__ __forceinline__ void tail16_step(const Gru16Args &p, const Tail16Lds &L, const LossScales &ls, const Tail16In &in, const f32x4 (&h)[4],
+                                            bool ok, int A, int lane, Tail16Acc<HEAD, NBH> &acc, f32x4 (&d)[4]) {
+  constexpr int DLS = NBH == 1 ? 20 : 36;
+  const int n = lane & 15, q = lane >> 4;
+  float *Uy = L.Uy, *Udl = L.Udl;
+  // ---- y = rnn.norm(h_t) (rnn.py:79) ----
+  f32x4 xh[4], y[4];
+  float mean, rstd;
+  {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) s += h[b];
+    mean = quad_sum16((s[0] + s[1]) + (s[2] + s[3])) * (1.f / HID);
+    const f32x4 mean4 = {mean, mean, mean, mean};
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { xh[b] = h[b] - mean4; v += xh[b] * xh[b]; }
+    rstd = 1.0f / sqrtf(quad_sum16((v[0] + v[1]) + (v[2] + v[3])) * (1.f / HID) + LN_EPS);
+    const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { xh[b] *= rstd4; y[b] = xh[b] * ld4(L.rn_g + 16 * b + 4 * q) + ld4(L.rn_b + 16 * b + 4 * q); }
+  }
+  f32x4 dy[4];
+  if constexpr (HEAD == 1) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, y[b]);
+    f32x4 zl[NBH];
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo) zl[bo] = ld4(L.bh + 16 * bo + 4 * q);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      f32x4 a[NBH];
+#pragma unroll
+      for (int bo = 0; bo < NBH; ++bo) a[bo] = ld4(L.wh + ((bo * 4 + b) * 64 + lane) * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int bo = 0; bo < NBH; ++bo) zl[bo] = mfma16(a[bo][i], y[b][i], zl[bo]);
+    }
+    actor_loss_q16<NBH>(zl, A, q, in.dead, (int)in.f0, in.f1, in.f2, in.f3, ok, p.cfg, ls.scale_pi, acc.lacc);
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo) st4(Udl + n * DLS + 16 * bo + 4 * q, zl[bo]);
+    wave_lds_sync();
+    dw_accum16<NBH, 4>(acc.gWh, acc.gBh, Udl, DLS, Uy, RS16, n, q);
+    // d y = Wh^T dl: out block bk, k-step (bo, i) takes action 16 bo + 4 q + i; A operand Wh[16 bo + 4 q + i][16 bk + n] sits in
+    // fragment (bo, bk) at lane' = (4 q + i, n >> 2), element n & 3
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) dy[bk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float *wt = L.wh + ((n >> 2) * 16 + 4 * q) * 4 + (n & 3);
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float a[4];
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk) a[bk] = wt[(bo * 4 + bk) * 256 + 4 * i];
+#pragma unroll
+        for (int bk = 0; bk < 4; ++bk) dy[bk] = mfma16(a[bk], zl[bo][i], dy[bk]);
+      }
+    wave_lds_sync();
+  } else {
+    f32x4 wv[4];
+    float sacc = 0.f;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      wv[b] = ld4(L.wh + 16 * b + 4 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sacc += wv[b][i] * y[b][i];
+    }
+    const float v = quad_sum16(sacc) + L.bh[0];
+    float dv = critic_loss16(v, in.f0, in.f1, in.f2, p.cfg, ls, ok && q == 0, acc.lacc);
+    dv = ok ? dv : 0.f;
+    if (q == 0) acc.gBh[0] += dv;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      st4(Uy + n * RS16 + 16 * b + 4 * q, y[b] * f32x4{dv, dv, dv, dv});
+      dy[b] = wv[b] * f32x4{dv, dv, dv, dv};
+    }
+    wave_lds_sync();
+    acc.gWc += col_sum16(Uy, RS16, lane);
+    wave_lds_sync();
+  }
+  // rnn.norm backward: d gamma = sum dy o xhat, d beta = sum dy (column sums through the wave's tile), then d h
+#pragma unroll
+  for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, dy[b] * xh[b]);
+  wave_lds_sync();
+  acc.gNw += col_sum16(Uy, RS16, lane);
+  wave_lds_sync();
+#pragma unroll
+  for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, dy[b]);
+  wave_lds_sync();
+  acc.gNb += col_sum16(Uy, RS16, lane);
+  wave_lds_sync();
+  {
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { dy[b] *= ld4(L.rn_g + 16 * b + 4 * q); s1 += dy[b]; s2 += dy[b] * xh[b]; }
+    const float m1 = quad_sum16((s1[0] + s1[1]) + (s1[2] + s1[3])) * (1.f / HID);
+    const float m2 = quad_sum16((s2[0] + s2[1]) + (s2[2] + s2[3])) * (1.f / HID);
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) d[b][i] = rstd * (dy[b][i] - m1 - xh[b][i] * m2);
+  }
+}
+
+// workgroup reduction of the waves' sums -> slab row `bid` and loss partials row `bid`.  red: [nw][NBH * 4][256] floats (actor),
+// vec: [nw][8][64]; the caller has made both areas free (a __syncthreads() after the last use of what they overlay).
+template <int HEAD, int NBH>
+__device__ __forceinline__ void tail16_epilogue(const Gru16Args &p, const Tail16Acc<HEAD, NBH> &acc, float *red, float *vec, int wave, int nw,
+                                                int lane, int bid) {
+  const NetOff &o = p.off;
+  const int A = p.A, nthr = blockDim.x;
+  if constexpr (HEAD == 1) {
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+      for (int bk = 0; bk < 4; ++bk) st4(red + ((wave * NBH * 4 + bo * 4 + bk) * 64 + lane) * 4, acc.gWh[bo][bk]);
+  }
+  vec[(wave * 8 + 0) * 64 + lane] = acc.gNw;
+  vec[(wave * 8 + 1) * 64 + lane] = acc.gNb;
+  if constexpr (HEAD == 1) {
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo) vec[(wave * 8 + 2 + bo) * 64 + lane] = quad_sum16(acc.gBh[bo]);
+  } else {
+    vec[(wave * 8 + 2) * 64 + lane] = acc.gWc;
+    const float sdv = wave_sum_f(acc.gBh[0]);
+    if (lane == 0) vec[(wave * 8 + 3) * 64] = sdv;
+  }
+  {
+    const float l0 = wave_sum_f(acc.lacc[0]), l1 = wave_sum_f(acc.lacc[1]), l2 = wave_sum_f(acc.lacc[2]);
+    if (lane == 0) { vec[(wave * 8 + 4) * 64 + 0] = l0; vec[(wave * 8 + 4) * 64 + 1] = l1; vec[(wave * 8 + 4) * 64 + 2] = l2; }
+  }
+  __syncthreads();
+  float *slab = p.slabs + (size_t)bid * p.slab_stride + p.slab_col0;
+  if constexpr (HEAD == 1) {
+    for (int e = threadIdx.x; e < NBH * 4 * 256; e += nthr) {
+      float s = 0.f;
+      for (int w = 0; w < nw; ++w) s += red[w * NBH * 4 * 256 + e];
+      const int blk = e >> 8, ln = (e >> 2) & 63, i = e & 3;
+      const int a = 16 * (blk >> 2) + 4 * (ln >> 4) + i, k = 16 * (blk & 3) + (ln & 15);
+      if (a < A) slab[o.wh + a * HID + k] = s;
+    }
+  }
+  for (int e = threadIdx.x; e < 4 * 64; e += nthr) {
+    const int which = e >> 6, k = e & 63;                        // 0: rn_w, 1: rn_b, 2: head vector 0, 3: head vector 1
+    float s = 0.f;
+    for (int w = 0; w < nw; ++w) s += vec[(w * 8 + which) * 64 + k];
+    if (which == 0) slab[o.rn_w + k] = s;
+    else if (which == 1) slab[o.rn_b + k] = s;
+    else if (HEAD == 1) {
+      const int a = 16 * (which - 2) + k;
+      if (k < 16 && which - 2 < NBH && a < A) slab[o.bh + a] = s;
+    } else if (which == 2) slab[o.wh + k] = s;
+    else if (k == 0) slab[o.bh] = s;
+  }
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = 0.0;
+      if (k < 3) for (int w = 0; w < nw; ++w) v += (double)vec[(w * 8 + 4) * 64 + k];
+      p.partials[(size_t)bid * 4 + k] = v;
+    }
+  }
+}
+
 // ================================================================================================================================
 // forward + head + loss + head backward
 // ================================================================================================================================
@@ -240,16 +455,9 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
   ls.scale_v = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.scale_v)));
   ls.vn_mean = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.vn_mean)));
   ls.vn_sd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.vn_sd)));
-  float lacc[3] = {0.f, 0.f, 0.f};
-  f32x4 gWh[HEAD == 1 ? NBH : 1][HEAD == 1 ? 4 : 1];
-  float gBh[HEAD == 1 ? NBH : 1];
-  float gWc = 0.f, gNw = 0.f, gNb = 0.f;                          // critic head product / rnn.norm gradients: lane = feature
-#pragma unroll
-  for (int bo = 0; bo < (HEAD == 1 ? NBH : 1); ++bo) {
-    gBh[bo] = 0.f;
-#pragma unroll
-    for (int bk = 0; bk < (HEAD == 1 ? 4 : 1); ++bk) gWh[bo][bk] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
+  Tail16Acc<HEAD, NBH> acc;
+  acc.clear();
+  const Tail16Lds TL = {lds + M::RN_G, lds + M::RN_B, lds + M::WH, lds + M::BH, Uy, Udl};
   const int n_ct = (p.Nc + 15) >> 4;
   const int64_t B = (int64_t)p.L * p.Nc;
   const int64_t CS = (int64_t)p.L * n_ct * 1024;                  // floats per scratch component
@@ -261,9 +469,18 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
     f32x4 h[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) h[b] = ld4(p.h0 + hrow * HID + 16 * b + 4 * q);
+    // the reset mask gates the first MFMA of a step, behind a two-deep dependent load (rows -> masks): the row index runs two steps
+    // ahead and the mask one step ahead, so a lone wave of a SIMD (small batches) does not wait for either
+    auto row_of = [&](int t) -> int64_t {
+      const int64_t col = (int64_t)min(t, p.L - 1) * p.Nc + cc;
+      return p.rows ? (int64_t)p.rows[col] : col;
+    };
+    int64_t brow = row_of(0), brow1 = row_of(1);
+    float mk = p.masks[brow];
     for (int t = 0; t < p.L; ++t) {
       const int64_t col = (int64_t)t * p.Nc + cc;
-      const int64_t brow = p.rows ? (int64_t)p.rows[col] : col;
+      const int64_t brow2 = row_of(t + 2);
+      const float mk1 = p.masks[brow1];
       // ---- this step's inputs: everything is requested before the first use ----
       f32x4 x[4];
       if constexpr (XBLK) {
@@ -276,30 +493,11 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
 #pragma unroll
           for (int i = 0; i < 4; ++i) x[b][i] = p.x[(int64_t)(16 * b + 4 * q + i) * B + col];
       }
-      float mk = p.masks[brow];
-      float f0, f1, f2, f3 = 0.f;
-      uint32_t dead = 0u;
-      if constexpr (HEAD == 1) {
-        f0 = p.actions[brow]; f1 = p.old_logp[brow]; f2 = p.adv[brow]; f3 = p.active[brow];
-        if (p.avail) {
-          const float *av = p.avail + brow * A;
-          float v[NBH][4];
-#pragma unroll
-          for (int bo = 0; bo < NBH; ++bo)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[bo][i] = av[min(16 * bo + 4 * q + i, A - 1)];
-#pragma unroll
-          for (int bo = 0; bo < NBH; ++bo)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dead |= ((16 * bo + 4 * q + i < A && v[bo][i] == 0.f) ? 1u : 0u) << (4 * bo + i);
-        }
-      } else {
-        f0 = p.v_old[brow]; f1 = p.returns[brow]; f2 = p.active[brow];
-      }
-      mk = ok ? mk : 0.f;
+      const Tail16In in = tail16_load<HEAD, NBH>(p, brow, q, A);
+      const float mk0 = ok ? mk : 0.f;
       f32x4 hm[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) hm[b] = h[b] * f32x4{mk, mk, mk, mk};
+      for (int b = 0; b < 4; ++b) hm[b] = h[b] * f32x4{mk0, mk0, mk0, mk0};
       // ---- gates: gi + gh, 384 MFMAs in four-accumulator groups ----
       f32x4 ar[4], az[4], ain[4], ahn[4];
 #pragma unroll
@@ -333,165 +531,16 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
         st4(sb + C_GHN * CS + b * 256, ahn[b]);
       }
       // ---- y = rnn.norm(h_t) (rnn.py:79), head, loss, and back to d h_t ----
-      f32x4 xh[4], y[4];
-      float mean, rstd;
-      {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      f32x4 d[4];
+      tail16_step<HEAD, NBH>(p, TL, ls, in, h, ok, A, lane, acc, d);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s += h[b];
-        mean = quad_sum16((s[0] + s[1]) + (s[2] + s[3])) * (1.f / HID);
-        const f32x4 mean4 = {mean, mean, mean, mean};
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { xh[b] = h[b] - mean4; v += xh[b] * xh[b]; }
-        rstd = 1.0f / sqrtf(quad_sum16((v[0] + v[1]) + (v[2] + v[3])) * (1.f / HID) + LN_EPS);
-        const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { xh[b] *= rstd4; y[b] = xh[b] * ld4(lds + M::RN_G + 16 * b + 4 * q) + ld4(lds + M::RN_B + 16 * b + 4 * q); }
-      }
-      f32x4 dy[4];
-      if constexpr (HEAD == 1) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, y[b]);
-        f32x4 zl[NBH];
-#pragma unroll
-        for (int bo = 0; bo < NBH; ++bo) zl[bo] = ld4(lds + M::BH + 16 * bo + 4 * q);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          f32x4 a[NBH];
-#pragma unroll
-          for (int bo = 0; bo < NBH; ++bo) a[bo] = ld4(lds + M::WH + ((bo * 4 + b) * 64 + lane) * 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int bo = 0; bo < NBH; ++bo) zl[bo] = mfma16(a[bo][i], y[b][i], zl[bo]);
-        }
-        actor_loss_q16<NBH>(zl, A, q, dead, (int)f0, f1, f2, f3, ok, p.cfg, ls.scale_pi, lacc);
-#pragma unroll
-        for (int bo = 0; bo < NBH; ++bo) st4(Udl + n * M::DLS + 16 * bo + 4 * q, zl[bo]);
-        wave_lds_sync();
-        dw_accum16<NBH, 4>(gWh, gBh, Udl, M::DLS, Uy, RS16, n, q);
-        // d y = Wh^T dl: out block bk, k-step (bo, i) takes action 16 bo + 4 q + i; A operand Wh[16 bo + 4 q + i][16 bk + n] sits in
-        // fragment (bo, bk) at lane' = (4 q + i, n >> 2), element n & 3
-#pragma unroll
-        for (int bk = 0; bk < 4; ++bk) dy[bk] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *wt = lds + M::WH + ((n >> 2) * 16 + 4 * q) * 4 + (n & 3);
-#pragma unroll
-        for (int bo = 0; bo < NBH; ++bo)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            float a[4];
-#pragma unroll
-            for (int bk = 0; bk < 4; ++bk) a[bk] = wt[(bo * 4 + bk) * 256 + 4 * i];
-#pragma unroll
-            for (int bk = 0; bk < 4; ++bk) dy[bk] = mfma16(a[bk], zl[bo][i], dy[bk]);
-          }
-        wave_lds_sync();
-      } else {
-        f32x4 wv[4];
-        float acc = 0.f;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          wv[b] = ld4(lds + M::WH + 16 * b + 4 * q);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) acc += wv[b][i] * y[b][i];
-        }
-        const float v = quad_sum16(acc) + lds[M::BH];
-        float dv = critic_loss16(v, f0, f1, f2, p.cfg, ls, ok && q == 0, lacc);
-        dv = ok ? dv : 0.f;
-        if (q == 0) gBh[0] += dv;
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          st4(Uy + n * RS16 + 16 * b + 4 * q, y[b] * f32x4{dv, dv, dv, dv});
-          dy[b] = wv[b] * f32x4{dv, dv, dv, dv};
-        }
-        wave_lds_sync();
-        gWc += col_sum16(Uy, RS16, lane);
-        wave_lds_sync();
-      }
-      // rnn.norm backward: d gamma = sum dy o xhat, d beta = sum dy (column sums through the wave's tile), then d h
-#pragma unroll
-      for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, dy[b] * xh[b]);
-      wave_lds_sync();
-      gNw += col_sum16(Uy, RS16, lane);
-      wave_lds_sync();
-#pragma unroll
-      for (int b = 0; b < 4; ++b) st4(Uy + n * RS16 + 16 * b + 4 * q, dy[b]);
-      wave_lds_sync();
-      gNb += col_sum16(Uy, RS16, lane);
-      wave_lds_sync();
-      {
-        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) { dy[b] *= ld4(lds + M::RN_G + 16 * b + 4 * q); s1 += dy[b]; s2 += dy[b] * xh[b]; }
-        const float m1 = quad_sum16((s1[0] + s1[1]) + (s1[2] + s1[3])) * (1.f / HID);
-        const float m2 = quad_sum16((s2[0] + s2[1]) + (s2[2] + s2[3])) * (1.f / HID);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          f32x4 d;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) d[i] = rstd * (dy[b][i] - m1 - xh[b][i] * m2);
-          st4(sb + C_DH * CS + b * 256, d);
-        }
-      }
+      for (int b = 0; b < 4; ++b) st4(sb + C_DH * CS + b * 256, d[b]);
+      brow = brow1; brow1 = brow2; mk = mk1;
     }
   }
   // ---- workgroup reduction -> slab row `bid`, loss partials ----
   __syncthreads();                                               // every wave is done with the weights: their area is free
-  float *red = lds;                                              // [wave][NBH * 4][256] head products | vectors behind them
-  float *vec = lds + G16_WAVES * NBH * 4 * 256;                  // [wave][8][64]: gNw, gNb, gWc | gBh[bo] (actor: lane n = action 16 bo + n), loss sums
-  const int nthr = blockDim.x;
-  if constexpr (HEAD == 1) {
-#pragma unroll
-    for (int bo = 0; bo < NBH; ++bo)
-#pragma unroll
-      for (int bk = 0; bk < 4; ++bk) st4(red + ((wave * NBH * 4 + bo * 4 + bk) * 64 + lane) * 4, gWh[bo][bk]);
-  }
-  vec[(wave * 8 + 0) * 64 + lane] = gNw;
-  vec[(wave * 8 + 1) * 64 + lane] = gNb;
-  if constexpr (HEAD == 1) {
-#pragma unroll
-    for (int bo = 0; bo < NBH; ++bo) vec[(wave * 8 + 2 + bo) * 64 + lane] = quad_sum16(gBh[bo]);
-  } else {
-    vec[(wave * 8 + 2) * 64 + lane] = gWc;
-    const float sdv = wave_sum_f(gBh[0]);
-    if (lane == 0) vec[(wave * 8 + 3) * 64] = sdv;
-  }
-  {
-    const float l0 = wave_sum_f(lacc[0]), l1 = wave_sum_f(lacc[1]), l2 = wave_sum_f(lacc[2]);
-    if (lane == 0) { vec[(wave * 8 + 4) * 64 + 0] = l0; vec[(wave * 8 + 4) * 64 + 1] = l1; vec[(wave * 8 + 4) * 64 + 2] = l2; }
-  }
-  __syncthreads();
-  float *slab = p.slabs + (size_t)bid * p.slab_stride + p.slab_col0;
-  if constexpr (HEAD == 1) {
-    for (int e = threadIdx.x; e < NBH * 4 * 256; e += nthr) {
-      float s = 0.f;
-      for (int w = 0; w < nw; ++w) s += red[w * NBH * 4 * 256 + e];
-      const int blk = e >> 8, ln = (e >> 2) & 63, i = e & 3;
-      const int a = 16 * (blk >> 2) + 4 * (ln >> 4) + i, k = 16 * (blk & 3) + (ln & 15);
-      if (a < A) slab[o.wh + a * HID + k] = s;
-    }
-  }
-  for (int e = threadIdx.x; e < 4 * 64; e += nthr) {
-    const int which = e >> 6, k = e & 63;                        // 0: rn_w, 1: rn_b, 2: head vector 0, 3: head vector 1
-    float s = 0.f;
-    for (int w = 0; w < nw; ++w) s += vec[(w * 8 + which) * 64 + k];
-    if (which == 0) slab[o.rn_w + k] = s;
-    else if (which == 1) slab[o.rn_b + k] = s;
-    else if (HEAD == 1) {
-      const int a = 16 * (which - 2) + k;
-      if (k < 16 && which - 2 < NBH && a < A) slab[o.bh + a] = s;
-    } else if (which == 2) slab[o.wh + k] = s;
-    else if (k == 0) slab[o.bh] = s;
-  }
-  if (threadIdx.x == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      double v = 0.0;
-      if (k < 3) for (int w = 0; w < nw; ++w) v += (double)vec[(w * 8 + 4) * 64 + k];
-      p.partials[(size_t)bid * 4 + k] = v;
-    }
-  }
+  tail16_epilogue<HEAD, NBH>(p, acc, lds, lds + G16_WAVES * NBH * 4 * 256, wave, nw, lane, bid);
 }
 
 template <int HEAD, int NBH, bool XBLK>
@@ -503,7 +552,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gru16_fwd_kernel(Gru16Args a) 
 // ================================================================================================================================
 // backward recurrence + d x
 // ================================================================================================================================
-template <bool DXBLK>
+template <bool DXBLK, bool PRE>
 __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, const int bid, const int nb) {
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
@@ -523,6 +572,19 @@ __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, c
     f32x4 carry[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) carry[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // PRE (one wave per SIMD: no partner to cover the latency, and 512 registers to spend): step t - 1's six vectors are requested
+    // at the top of step t and land under its 384 MFMAs
+    f32x4 pf[PRE ? 6 : 1][4];
+    auto load6 = [&](f32x4 (&d)[PRE ? 6 : 1][4], const float *s0) {
+      if constexpr (PRE) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          d[0][b] = ld4(s0 + C_DH * CS + b * 256); d[1][b] = ld4(s0 + C_Z * CS + b * 256); d[2][b] = ld4(s0 + C_N * CS + b * 256);
+          d[3][b] = ld4(s0 + C_R * CS + b * 256); d[4][b] = ld4(s0 + C_GHN * CS + b * 256); d[5][b] = ld4(s0 + C_HM * CS + b * 256);
+        }
+      }
+    };
+    load6(pf, p.scratch + ((int64_t)((p.L - 1) * n_ct + tile) * 4) * 256 + lane * 4);
     for (int t = p.L - 1; t >= 0; --t) {
       // (compiler fence: without it hipcc hoists the NEXT step's 24 loads above this step's MFMA phase — 96 more live registers,
       // 124 of them spilled; the partner wave of the SIMD covers the load latency instead)
@@ -531,14 +593,20 @@ __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, c
       const int64_t brow = p.rows ? (int64_t)p.rows[col] : col;
       float *sb = p.scratch + ((int64_t)(t * n_ct + tile) * 4) * 256 + lane * 4;
       f32x4 dh[4], hm[4], gr[4], gz[4], gn[4], ghn[4];
+      if constexpr (PRE) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        dh[b] = ld4(sb + C_DH * CS + b * 256);
-        gz[b] = ld4(sb + C_Z * CS + b * 256);
-        gn[b] = ld4(sb + C_N * CS + b * 256);
-        gr[b] = ld4(sb + C_R * CS + b * 256);
-        ghn[b] = ld4(sb + C_GHN * CS + b * 256);
-        hm[b] = ld4(sb + C_HM * CS + b * 256);
+        for (int b = 0; b < 4; ++b) { dh[b] = pf[0][b]; gz[b] = pf[1][b]; gn[b] = pf[2][b]; gr[b] = pf[3][b]; ghn[b] = pf[4][b]; hm[b] = pf[5][b]; }
+        if (t > 0) load6(pf, sb - (int64_t)n_ct * 1024);
+      } else {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          dh[b] = ld4(sb + C_DH * CS + b * 256);
+          gz[b] = ld4(sb + C_Z * CS + b * 256);
+          gn[b] = ld4(sb + C_N * CS + b * 256);
+          gr[b] = ld4(sb + C_R * CS + b * 256);
+          ghn[b] = ld4(sb + C_GHN * CS + b * 256);
+          hm[b] = ld4(sb + C_HM * CS + b * 256);
+        }
       }
       float mk = p.masks[brow];
       mk = ok ? mk : 0.f;
@@ -604,7 +672,301 @@ __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, c
 template <bool DXBLK>
 __global__ __launch_bounds__(G16_THREADS, 2) void gru16_bwd_kernel(Gru16Args a) {
   extern __shared__ __align__(16) float lds[];
-  gru16_bwd_body<DXBLK>(a, lds, blockIdx.x, gridDim.x);
+  gru16_bwd_body<DXBLK, false>(a, lds, blockIdx.x, gridDim.x);
+}
+// at most four waves per workgroup (small batches, seq_waves()): one wave per SIMD, so the whole register file is the wave's
+template <bool DXBLK>
+__global__ __launch_bounds__(4 * WAVE, 1) void gru16_bwd4_kernel(Gru16Args a) {
+  extern __shared__ __align__(16) float lds[];
+  gru16_bwd_body<DXBLK, true>(a, lds, blockIdx.x, gridDim.x);
+}
+
+// ================================================================================================================================
+// small batches: the same pass when the tile count cannot fill the chip with one wave per tile
+// ================================================================================================================================
+// With n_ct <= ~4 tiles per CU the kernels above run one wave per SIMD, each alone with the whole 444-MFMA + gate + head chain of
+// its tile's step (config-2 rmappo: 29k cycles per step, MFMA pipe 50 % idle, half of the SIMDs empty).  Here a tile's step is
+// split over the FOUR waves of a workgroup by output-feature block (wave j: features 16 j .. 16 j + 15 of every gate — 96 MFMAs,
+// a quarter of the gate arithmetic), the weights of a wave (2 x 48 rows x 64) stay in REGISTERS as A operands (no LDS staging,
+// no LDS weight traffic), h_t / the d-gates are exchanged through a double-buffered LDS tile with ONE barrier per step, and
+// the per-row tail (rnn.norm, head, loss, their backward) — which has no time dependence — leaves the recurrence and runs as a
+// parallel pass over all (t, tile) row tiles (gru16_head_kernel).  Scratch layout and contents are those of the kernels above
+// (during the forward, component C_DH carries h_t from gru16s_fwd_kernel to gru16_head_kernel, which overwrites it with d h_t).
+template <bool XBLK>
+__global__ __launch_bounds__(4 * WAVE) void gru16s_fwd_kernel(Gru16Args p) {
+  __shared__ __align__(16) float ex[2][4 * 256];                  // h_t, blocked [b][lane][4]
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
+  const int j = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int n_ct = (p.Nc + 15) >> 4;
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t CS = (int64_t)p.L * n_ct * 1024;
+  // A operands: lane (m = n, k quarter q) of out block j, k-step (b, i): W[gate * 64 + 16 j + n][16 b + 4 q + i]
+  f32x4 wh[3][4], wi[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      wh[g][b] = ld4(p.params + o.gru_whh + (g * HID + 16 * j + n) * HID + 16 * b + 4 * q);
+      wi[g][b] = ld4(p.params + o.gru_wih + (g * HID + 16 * j + n) * HID + 16 * b + 4 * q);
+    }
+  const int fo = 16 * j + 4 * q;                                  // the lane's four features
+  const f32x4 b_r = ld4(p.params + o.gru_bih + fo) + ld4(p.params + o.gru_bhh + fo);
+  const f32x4 b_z = ld4(p.params + o.gru_bih + HID + fo) + ld4(p.params + o.gru_bhh + HID + fo);
+  const f32x4 b_in = ld4(p.params + o.gru_bih + 2 * HID + fo), b_hn = ld4(p.params + o.gru_bhh + 2 * HID + fo);
+  for (int tile = blockIdx.x; tile < n_ct; tile += gridDim.x) {   // (the weights stay in registers across a workgroup's tiles)
+  const int c = tile * 16 + n;
+  const bool ok = c < p.Nc;
+  const int cc = ok ? c : 0;
+  const int64_t hrow = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
+  __syncthreads();                                                // the previous tile's last reads of ex[] are done
+  st4(&ex[0][j * 256 + lane * 4], ld4(p.h0 + hrow * HID + fo));
+  auto row_of = [&](int t) -> int64_t {
+    const int64_t col = (int64_t)min(t, p.L - 1) * p.Nc + cc;
+    return p.rows ? (int64_t)p.rows[col] : col;
+  };
+  auto load_x = [&](f32x4 (&x)[4], int t) {
+    const int tt = min(t, p.L - 1);
+    if constexpr (XBLK) {
+      const float *xb = p.x + ((int64_t)(tt * n_ct + tile) * 4) * 256 + lane * 4;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) x[b] = ld4(xb + b * 256);
+    } else {
+      const int64_t col = (int64_t)tt * p.Nc + cc;
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[b][i] = p.x[(int64_t)(16 * b + 4 * q + i) * B + col];
+    }
+  };
+  int64_t brow1 = row_of(1);
+  float mk = p.masks[row_of(0)];
+  f32x4 x[4];
+  load_x(x, 0);
+  for (int t = 0; t < p.L; ++t) {
+    const int64_t brow2 = row_of(t + 2);
+    const float mk1 = p.masks[brow1];
+    // input-side products first: they do not wait for the other waves' h_{t-1}
+    f32x4 ar = b_r, az = b_z, ain = b_in, ahn = b_hn;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ar = mfma16(wi[0][b][i], x[b][i], ar);
+        az = mfma16(wi[1][b][i], x[b][i], az);
+        ain = mfma16(wi[2][b][i], x[b][i], ain);
+      }
+    load_x(x, t + 1);                                             // lands under the recurrent half
+    __syncthreads();                                              // ex[t & 1] = h_{t-1} is complete
+    const float *e = ex[t & 1];
+    const float mk0 = ok ? mk : 0.f;
+    const f32x4 mk4 = {mk0, mk0, mk0, mk0};
+    f32x4 hm[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) hm[b] = ld4(e + b * 256 + lane * 4) * mk4;
+    const f32x4 hmj = ld4(e + j * 256 + lane * 4) * mk4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        ar = mfma16(wh[0][b][i], hm[b][i], ar);
+        az = mfma16(wh[1][b][i], hm[b][i], az);
+        ahn = mfma16(wh[2][b][i], hm[b][i], ahn);
+      }
+    f32x4 r, z, nn, hn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[i] = sigmoid16(ar[i]);
+      z[i] = sigmoid16(az[i]);
+      nn[i] = tanh16(ain[i] + r[i] * ahn[i]);
+      hn[i] = (1.f - z[i]) * nn[i] + z[i] * hmj[i];
+    }
+    st4(&ex[(t + 1) & 1][j * 256 + lane * 4], hn);                // read after the next step's barrier
+    float *sb = p.scratch + ((int64_t)(t * n_ct + tile) * 4) * 256 + j * 256 + lane * 4;
+    st4(sb + C_HM * CS, hmj);
+    st4(sb + C_R * CS, r);
+    st4(sb + C_Z * CS, z);
+    st4(sb + C_N * CS, nn);
+    st4(sb + C_GHN * CS, ahn);
+    st4(sb + C_DH * CS, hn);                                      // h_t for gru16_head_kernel
+    brow1 = brow2; mk = mk1;
+  }
+  }
+}
+
+template <int HEAD, int NBH>
+struct H16Lds {
+  static constexpr int DLS = NBH == 1 ? 20 : 36;
+  static constexpr int NW = 4;
+  static constexpr int RN_G = 0, RN_B = RN_G + HID, WH = RN_B + HID, BH = WH + (HEAD == 1 ? NBH * 4 * 256 : HID), TILES = BH + 32;
+  static constexpr int WAVE_STRIDE = 16 * RS16 + (HEAD == 1 ? 16 * DLS : 0);
+  static constexpr int RED = TILES;                              // the epilogue's sums overlay the waves' tiles (after a barrier)
+  static constexpr int RED_N = HEAD == 1 ? NW * NBH * 4 * 256 : 0;
+  static constexpr int VEC = TILES + (RED_N > NW * WAVE_STRIDE ? RED_N : NW * WAVE_STRIDE), TOTAL = VEC + NW * 8 * 64;
+  static_assert(TOTAL * 4 <= 64 * 1024, "gru16 head: static LDS");
+};
+
+// rnn.norm + head + loss + their backward over ALL (t, tile) row tiles: h_t (scratch C_DH) -> d h_t in place
+template <int HEAD, int NBH>
+__global__ __launch_bounds__(4 * WAVE) void gru16_head_kernel(Gru16Args p) {
+  typedef H16Lds<HEAD, NBH> M;
+  __shared__ __align__(16) float lds[M::TOTAL];
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int A = p.A;
+  for (int e = threadIdx.x; e < 2 * HID + 32; e += blockDim.x) {
+    if (e < HID) lds[M::RN_G + e] = p.params[o.rn_w + e];
+    else if (e < 2 * HID) lds[M::RN_B + (e - HID)] = p.params[o.rn_b + (e - HID)];
+    else {
+      const int a = e - 2 * HID;
+      lds[M::BH + a] = a < A ? p.params[o.bh + a] : 0.f;
+    }
+  }
+  if constexpr (HEAD == 1) stage_frag<2>(lds + M::WH, p.params + o.wh, 16 * NBH, HID, A);
+  else { if (threadIdx.x < HID) lds[M::WH + threadIdx.x] = p.params[o.wh + threadIdx.x]; }
+  __syncthreads();
+  LossScales ls = loss_scales(p.cfg, p.mb_moments, p.vn_state);
+  ls.scale_pi = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.scale_pi)));
+  ls.scale_v = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.scale_v)));
+  ls.vn_mean = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.vn_mean)));
+  ls.vn_sd = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(ls.vn_sd)));
+  Tail16Acc<HEAD, NBH> acc;
+  acc.clear();
+  float *Uy = lds + M::TILES + wave * M::WAVE_STRIDE;
+  const Tail16Lds TL = {lds + M::RN_G, lds + M::RN_B, lds + M::WH, lds + M::BH, Uy, Uy + 16 * RS16};
+  const int n_ct = (p.Nc + 15) >> 4, n_rt = p.L * n_ct;
+  const int64_t CS = (int64_t)p.L * n_ct * 1024;
+  const int stride = gridDim.x * M::NW;
+  auto brow_of = [&](int rt) -> int64_t {                         // (clamped: the tile after a wave's last is a repeat, discarded)
+    const int r = min(rt, n_rt - 1), t = r / n_ct, c = (r - t * n_ct) * 16 + n;
+    const int64_t col = (int64_t)t * p.Nc + (c < p.Nc ? c : 0);
+    return p.rows ? (int64_t)p.rows[col] : col;
+  };
+  auto load_tile = [&](f32x4 (&h)[4], Tail16In &in, int rt, int64_t brow) {
+    const float *sb = p.scratch + C_DH * CS + (int64_t)min(rt, n_rt - 1) * 1024 + lane * 4;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) h[b] = ld4(sb + b * 256);
+    in = tail16_load<HEAD, NBH>(p, brow, q, A);
+  };
+  // a row's inputs sit behind a two-deep gather (rows -> loss inputs): row indices run two tiles ahead, the inputs one
+  int rt = blockIdx.x * M::NW + wave;
+  f32x4 h[4], hn[4];
+  Tail16In in, inn;
+  int64_t brow1 = brow_of(rt + stride);
+  load_tile(h, in, rt, brow_of(rt));
+  for (; rt < n_rt; rt += stride) {
+    const int64_t brow2 = brow_of(rt + 2 * stride);
+    load_tile(hn, inn, rt + stride, brow1);
+    const int t = rt / n_ct, tile = rt - t * n_ct;
+    const bool ok = tile * 16 + n < p.Nc;
+    float *sb = p.scratch + C_DH * CS + (int64_t)rt * 1024 + lane * 4;
+    f32x4 d[4];
+    tail16_step<HEAD, NBH>(p, TL, ls, in, h, ok, A, lane, acc, d);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { st4(sb + b * 256, d[b]); h[b] = hn[b]; }
+    in = inn; brow1 = brow2;
+  }
+  __syncthreads();                                               // every wave is done with its tiles: the sums overlay them
+  tail16_epilogue<HEAD, NBH>(p, acc, lds + M::RED, lds + M::VEC, wave, M::NW, lane, blockIdx.x);
+}
+
+// reverse time, wave j = out block j of the carry AND of d x; the four d-gate tiles of a step go through LDS
+template <bool DXBLK>
+__global__ __launch_bounds__(4 * WAVE) void gru16s_bwd_kernel(Gru16Args p) {
+  __shared__ __align__(16) float ex[2][4][4 * 256];               // [buffer][d_r, d_z, d_n, d_hn][b][lane][4]
+  const NetOff &o = p.off;
+  const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
+  const int j = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+  const int n_ct = (p.Nc + 15) >> 4;
+  const int64_t B = (int64_t)p.L * p.Nc;
+  const int64_t CS = (int64_t)p.L * n_ct * 1024;
+  // A operands of W^T: lane (m = n, q) of out block j, k-step (gate, b, i): W[gate * 64 + 16 b + 4 q + i][16 j + n]
+  f32x4 wh[3][4], wi[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wh[g][b][i] = p.params[o.gru_whh + (g * HID + 16 * b + 4 * q + i) * HID + 16 * j + n];
+        wi[g][b][i] = p.params[o.gru_wih + (g * HID + 16 * b + 4 * q + i) * HID + 16 * j + n];
+      }
+  for (int tile = blockIdx.x; tile < n_ct; tile += gridDim.x) {   // (a tile's first two steps write both buffers only after
+  const int c = tile * 16 + n;                                    // barriers every wave reaches once done with the previous tile)
+  const bool ok = c < p.Nc;
+  const int cc = ok ? c : 0;
+  f32x4 carry = {0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  struct Step { f32x4 dh, z, nn, r, ghn, hm; float mk; };
+  auto load_step = [&](Step &s, int t) {
+    const int tt = max(t, 0);
+    const float *sb = p.scratch + ((int64_t)(tt * n_ct + tile) * 4) * 256 + j * 256 + lane * 4;
+    s.dh = ld4(sb + C_DH * CS); s.z = ld4(sb + C_Z * CS); s.nn = ld4(sb + C_N * CS);
+    s.r = ld4(sb + C_R * CS); s.ghn = ld4(sb + C_GHN * CS); s.hm = ld4(sb + C_HM * CS);
+    const int64_t col = (int64_t)tt * p.Nc + cc;
+    s.mk = p.masks[p.rows ? (int64_t)p.rows[col] : col];
+  };
+  Step cur, nxt;
+  load_step(cur, p.L - 1);
+  for (int t = p.L - 1; t >= 0; --t) {
+    load_step(nxt, t - 1);                                        // own block only (6 KiB per wave): one step ahead
+    float *sb = p.scratch + ((int64_t)(t * n_ct + tile) * 4) * 256 + j * 256 + lane * 4;
+    f32x4 dhh, d_r, d_z, d_n, d_hn;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      dhh[i] = (ok ? cur.dh[i] : 0.f) + carry[i];
+      const float zz = cur.z[i], nn = cur.nn[i], rr = cur.r[i];
+      d_n[i] = dhh[i] * (1.f - zz) * (1.f - nn * nn);
+      d_r[i] = d_n[i] * cur.ghn[i] * rr * (1.f - rr);
+      d_hn[i] = d_n[i] * rr;
+      d_z[i] = dhh[i] * (cur.hm[i] - nn) * zz * (1.f - zz);
+    }
+    float *e = &ex[t & 1][0][0];
+    st4(e + 0 * 1024 + j * 256 + lane * 4, d_r);
+    st4(e + 1 * 1024 + j * 256 + lane * 4, d_z);
+    st4(e + 2 * 1024 + j * 256 + lane * 4, d_n);
+    st4(e + 3 * 1024 + j * 256 + lane * 4, d_hn);
+    st4(sb + C_R * CS, d_r);
+    st4(sb + C_Z * CS, d_z);
+    st4(sb + C_N * CS, d_n);
+    st4(sb + C_GHN * CS, d_hn);
+    __syncthreads();                                              // (the buffer is rewritten two steps later: one barrier per step)
+    // carry block j = W_hh^T [d_r, d_z, d_hn], d x block j = W_ih^T [d_r, d_z, d_n]: two accumulators each (even / odd k-steps)
+    f32x4 ca[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, xa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const f32x4 v = ld4(e + g * 1024 + b * 256 + lane * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ca[i & 1] = mfma16(wh[g][b][i], v[i], ca[i & 1]);
+          xa[i & 1] = mfma16(wi[g][b][i], v[i], xa[i & 1]);
+        }
+      }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const f32x4 vn = ld4(e + 2 * 1024 + b * 256 + lane * 4), vh = ld4(e + 3 * 1024 + b * 256 + lane * 4);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        xa[i & 1] = mfma16(wi[2][b][i], vn[i], xa[i & 1]);
+        ca[i & 1] = mfma16(wh[2][b][i], vh[i], ca[i & 1]);
+      }
+    }
+    const f32x4 dx = xa[0] + xa[1];
+    if constexpr (DXBLK) st4(sb + C_DH * CS, dx);
+    else if (ok) {
+      const int64_t col = (int64_t)t * p.Nc + cc;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) p.dxT[(int64_t)(16 * j + 4 * q + i) * B + col] = dx[i];
+    }
+    const float mk = ok ? cur.mk : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) carry[i] = (ca[0][i] + ca[1][i] + dhh[i] * cur.z[i]) * mk;
+    cur = nxt;
+  }
+  }
 }
 
 // ================================================================================================================================
@@ -864,6 +1226,26 @@ static int seq_waves(int Nc) {
   if (const char *e = getenv("MAPPO_GRU16_WAVES")) w = atoi(e);      // diagnostic override (scripts/phase_split.py A/B)
   return w < 1 ? 1 : (w > G16_WAVES ? G16_WAVES : w);
 }
+// Tile count up to which a tile's step is split over four waves (gru16s_* + gru16_head_kernel).  Measured train() ms, unsplit /
+// split (scripts/phase_split_n.py with MAPPO_GRU16_SPLIT_TILES[_BWD] = 0 | 4096): config-2 rmappo (384 tiles) 4.80 / 4.69; config 4
+// at 64 threads (1600 tiles) 12.28 / 12.09; config 3 (1920 tiles) 22.88 / 23.56 — with >= 4 tiles per CU the unsplit kernels already
+// keep two waves on every SIMD and both forms are bound by the same MFMA + gate arithmetic, the split one paying four x-tile reads
+// and a barrier per step on top.  MAPPO_GRU16_SPLIT_TILES / _BWD: A/B overrides.
+static bool seq_split(int Nc, bool bwd) {
+  int thr = 1024;
+  if (const char *e = getenv(bwd ? "MAPPO_GRU16_SPLIT_TILES_BWD" : "MAPPO_GRU16_SPLIT_TILES")) thr = atoi(e);
+  return (Nc + 15) / 16 <= thr;
+}
+static int split_grid(int Nc) {                                   // two workgroups of the split kernels fit a CU (registers)
+  const int n_ct = (Nc + 15) / 16;
+  int cap = 2 * NUM_CU;
+  if (const char *e = getenv("MAPPO_GRU16_SPLIT_GRID")) cap = atoi(e);
+  return n_ct < cap ? n_ct : cap;
+}
+static int head_grid(int L, int Nc) {
+  const int n_rt = L * ((Nc + 15) / 16), want = (n_rt + 3) / 4;
+  return want < NUM_CU ? want : NUM_CU;
+}
 static int seq_grid(int Nc) {
   const int n_ct = (Nc + 15) / 16, nw = seq_waves(Nc), want = (n_ct + nw - 1) / nw;
   return want < NUM_CU ? want : NUM_CU;
@@ -876,7 +1258,7 @@ static int wg_grid(int L, int Nc) {
 extern "C" int64_t mappo_gru16_scratch_floats(int32_t L, int32_t Nc) { return (int64_t)G16_COMPS * L * ((Nc + 15) / 16) * 1024; }
 extern "C" int64_t mappo_gru16_blocked_floats(int32_t L, int32_t Nc) { return (int64_t)L * ((Nc + 15) / 16) * 1024; }
 extern "C" int32_t mappo_gru16_slabs(int32_t L, int32_t Nc) {
-  const int a = seq_grid(Nc), b = wg_grid(L, Nc);
+  const int a = seq_grid(Nc), b = wg_grid(L, Nc);                 // (head_grid(L, Nc) <= wg_grid(L, Nc))
   return a > b ? a : b;
 }
 
@@ -944,11 +1326,30 @@ extern "C" int mappo_gru16_forward_loss(const float *params, const mappo_net_des
   const dim3 grid((unsigned)seq_grid(Nc));
   const hipStream_t st = as_stream(stream);
   int rc;
+  if (seq_split(Nc, false)) {                                     // recurrence split over four waves per tile, then the row-parallel tail
+    const dim3 g1((unsigned)split_grid(Nc)), g2((unsigned)head_grid(L, Nc)), blk(4 * WAVE);
+    if (x_blocked) hipLaunchKernelGGL(gru16s_fwd_kernel<true>, g1, blk, 0, st, a);
+    else hipLaunchKernelGGL(gru16s_fwd_kernel<false>, g1, blk, 0, st, a);
+    if (head == 2) hipLaunchKernelGGL((gru16_head_kernel<2, 1>), g2, blk, 0, st, a);
+    else if (a.A <= 16) hipLaunchKernelGGL((gru16_head_kernel<1, 1>), g2, blk, 0, st, a);
+    else hipLaunchKernelGGL((gru16_head_kernel<1, 2>), g2, blk, 0, st, a);
+    MAPPO_CHECK_LAUNCH("gru16_forward_loss");
+    return MAPPO_OK;
+  }
   if (head == 2) rc = x_blocked ? fwd16_launch<2, 1, true>(a, grid, st) : fwd16_launch<2, 1, false>(a, grid, st);
   else if (a.A <= 16) rc = x_blocked ? fwd16_launch<1, 1, true>(a, grid, st) : fwd16_launch<1, 1, false>(a, grid, st);
   else rc = x_blocked ? fwd16_launch<1, 2, true>(a, grid, st) : fwd16_launch<1, 2, false>(a, grid, st);
   if (rc) return rc;
   MAPPO_CHECK_LAUNCH("gru16_forward_loss");
+  return MAPPO_OK;
+}
+
+template <bool DXBLK, bool PRE>
+static int bwd16_launch(const Gru16Args &a, dim3 grid, int nw, size_t lds_bytes, hipStream_t st) {
+  void (*const fn)(Gru16Args) = PRE ? gru16_bwd4_kernel<DXBLK> : gru16_bwd_kernel<DXBLK>;
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+  if (e_ != hipSuccess) { mappo_set_error("gru16_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  hipLaunchKernelGGL(fn, grid, dim3(WAVE * nw), lds_bytes, st, a);
   return MAPPO_OK;
 }
 
@@ -961,15 +1362,18 @@ extern "C" int mappo_gru16_backward(const float *params, const mappo_net_desc *d
   a.params = params; a.off = net_offsets(*desc); a.masks = masks; a.rows = rows; a.L = L; a.Nc = Nc; a.scratch = scratch; a.dxT = dxT;
   const dim3 grid((unsigned)seq_grid(Nc));
   const size_t lds_bytes = (size_t)2 * G16_NG * HID * sizeof(float);
-  if (dxT) {
-    static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    if (e_ != hipSuccess) { mappo_set_error("gru16_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    hipLaunchKernelGGL(gru16_bwd_kernel<false>, grid, dim3(WAVE * seq_waves(Nc)), lds_bytes, as_stream(stream), a);
-  } else {
-    static const hipError_t e_ = hipFuncSetAttribute((const void *)gru16_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    if (e_ != hipSuccess) { mappo_set_error("gru16_backward: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-    hipLaunchKernelGGL(gru16_bwd_kernel<true>, grid, dim3(WAVE * seq_waves(Nc)), lds_bytes, as_stream(stream), a);
+  const hipStream_t st = as_stream(stream);
+  if (seq_split(Nc, true)) {
+    const dim3 g1((unsigned)split_grid(Nc)), blk(4 * WAVE);
+    if (dxT) hipLaunchKernelGGL(gru16s_bwd_kernel<false>, g1, blk, 0, st, a);
+    else hipLaunchKernelGGL(gru16s_bwd_kernel<true>, g1, blk, 0, st, a);
+    MAPPO_CHECK_LAUNCH("gru16_backward");
+    return MAPPO_OK;
   }
+  const int nw = seq_waves(Nc);
+  const int rc = nw <= 4 ? (dxT ? bwd16_launch<false, true>(a, grid, nw, lds_bytes, st) : bwd16_launch<true, true>(a, grid, nw, lds_bytes, st))
+                         : (dxT ? bwd16_launch<false, false>(a, grid, nw, lds_bytes, st) : bwd16_launch<true, false>(a, grid, nw, lds_bytes, st));
+  if (rc) return rc;
   MAPPO_CHECK_LAUNCH("gru16_backward");
   return MAPPO_OK;
 }
