@@ -159,6 +159,7 @@ def parse():
     ap.add_argument("--num_mini_batch", type=int, default=None)
     ap.add_argument("--exact_minibatch_order", action="store_true")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_companion", action="store_true", help="N > 1: skip the weak-scaling companion measurement")
     ap.add_argument("--cpu_threads", type=int, default=0, help="0 = all cores of this box (max 16)")
     ap.add_argument("--dry_launch", action="store_true",
                     help="launcher rehearsal without a GPU: every rank prints its RANK / WORLD_SIZE / LOCAL_RANK and exits (CPU test of --gpus N)")
@@ -462,6 +463,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- N > 1: the same K steps with the per-GPU work FIXED (weak scaling: configs[1]'s 1024 threads on EVERY rank) as a
+    # companion figure — `value` above stays the strong-scaling number north_star asks for; a 1.3 ms iteration of ~50 dependent
+    # launches cannot strong-scale, and the pair shows how much of the gap is launch latency and how much is the all-reduce ----
+    companion = None
+    if (world > 1 or force_dp) and ns.scaling == "strong" and not ns.no_companion:
+        import copy
+        args_w = copy.copy(args)
+        args_w.n_rollout_threads = ns.n_rollout_threads
+        if ns.env == "mpe":
+            env_w = SimpleSpreadVecEnv(args_w.n_rollout_threads, M, 3, args_w.episode_length, seed=101 + rank, device=device)
+        else:
+            env_w = SyntheticMPEEnv(args_w.n_rollout_threads, M, D, A, args_w.episode_length, seed=101 + rank, device=device)
+        torch.manual_seed(args.seed)
+        runner_w = MPERunner(dict(all_args=args_w, envs=env_w, eval_envs=None, num_agents=M, device=device, run_dir=None, dist_group=dp))
+        runner_w.warmup()
+        for i in range(max(ns.warmup, 2)):
+            runner_w.run_episode(i, ns.warmup + ns.steps)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(ns.steps):
+            runner_w.run_episode(ns.warmup + i, ns.warmup + ns.steps)
+        barrier()
+        dt_w = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dt_w], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_w = float(t.item())
+        steps_w = args_w.episode_length * args_w.n_rollout_threads * world * M
+        companion = dict(scaling="weak", value=steps_w * ns.steps / dt_w, unit="agent-steps/s", ms_per_step=1e3 * dt_w / ns.steps,
+                         n_rollout_threads_global=args_w.n_rollout_threads * world, n_rollout_threads_per_rank=args_w.n_rollout_threads,
+                         steps=ns.steps, note="same run, same ranks, same timing contract; per-GPU work fixed at configs[1]'s size")
+        del runner_w, env_w
+
     # ---- device time of the two phases of a step (same hipGraph path, three more iterations, HIP events) ----
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     ph = [0.0, 0.0]
@@ -527,6 +562,7 @@ def main():
                            agent_steps_per_step=global_steps, parallelism=f"dp{world}", rccl_ranks=ns.rccl_ranks,
                            exact_minibatch_order=bool(args.exact_minibatch_order), hip_graph=bool(graph_flags[1])),
                roofline=roofline, ppo_loss_roofline=loss_roof, gae_roofline=gae_roof, kernels_us=kern, phase_ms=phase_ms,
+               weak_scaling_companion=companion,
                last_train_info={k: float(v) for k, v in info.items()})
     if rank == 0:
         if world == 1 and not ns.no_cpu_baseline:
