@@ -1327,20 +1327,22 @@ int wide16_launch_recurrent_step_dual(bool relu, int ln, size_t lds_bytes, hipSt
 #define WIDE_SK_MAX_TILES 256          // per network: above, the streamed kernels fill the chip
 
 #ifdef MLP_TU_WIDE
-template <int NCH>
+template <int NCH, bool FULL>
 static int wide16_l1_fwd_one(const Wide16Args &w, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_fwd16_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_fwd16_kernel<NCH, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
   if (e_ != hipSuccess) { mappo_set_error("wide_l1_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-  hipLaunchKernelGGL((wide_l1_fwd16_kernel<NCH>), grid, dim3(512), lds_bytes, st, w);
+  hipLaunchKernelGGL((wide_l1_fwd16_kernel<NCH, FULL>), grid, dim3(512), lds_bytes, st, w);
   return MAPPO_OK;
 }
 int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
   const int nch = (w.D + 63) / 64;
   const size_t lds_bytes = sizeof(float) * ((size_t)HID * 64 * nch + HID);            // W1' whole (fragment order) + folded bias
-  if (nch <= 2) return wide16_l1_fwd_one<2>(w, grid, lds_bytes, st);
-  if (nch <= 4) return wide16_l1_fwd_one<4>(w, grid, lds_bytes, st);
-  if (nch <= 6) return wide16_l1_fwd_one<6>(w, grid, lds_bytes, st);
-  return wide16_l1_fwd_one<8>(w, grid, lds_bytes, st);
+  if (w.D == 512) return wide16_l1_fwd_one<8, true>(w, grid, lds_bytes, st);         // whole chunks: branch-free tile loop
+  if (w.D == 256) return wide16_l1_fwd_one<4, true>(w, grid, lds_bytes, st);
+  if (nch <= 2) return wide16_l1_fwd_one<2, false>(w, grid, lds_bytes, st);
+  if (nch <= 4) return wide16_l1_fwd_one<4, false>(w, grid, lds_bytes, st);
+  if (nch <= 6) return wide16_l1_fwd_one<6, false>(w, grid, lds_bytes, st);
+  return wide16_l1_fwd_one<8, false>(w, grid, lds_bytes, st);
 }
 
 #endif
@@ -1499,10 +1501,15 @@ int wide16_launch_features_dual(bool relu, int ln, bool small, dim3 grid, dim3 b
               : wide16_launch_features_dual_r<false>(ln, grid, block, lds_bytes, st, wa, a, wc, c, nA);
 }
 
+template <bool FN, bool GATHER>
+static void wide16_l1_bwd_one(const WideBwd16Args &w, dim3 grid, hipStream_t st) {
+  if ((w.D & 63) == 0) hipLaunchKernelGGL((wide_l1_bwd16_kernel<FN, GATHER, true>), grid, dim3(512), 0, st, w);      // whole chunks: branch-free tile loop
+  else hipLaunchKernelGGL((wide_l1_bwd16_kernel<FN, GATHER, false>), grid, dim3(512), 0, st, w);
+}
 int wide16_launch_l1_bwd(const WideBwd16Args &w, dim3 grid, hipStream_t st) {
   const bool fn = w.fn_w >= 0;
-  if (w.rows) { if (fn) hipLaunchKernelGGL((wide_l1_bwd16_kernel<true, true>), grid, dim3(512), 0, st, w); else hipLaunchKernelGGL((wide_l1_bwd16_kernel<false, true>), grid, dim3(512), 0, st, w); }
-  else { if (fn) hipLaunchKernelGGL((wide_l1_bwd16_kernel<true, false>), grid, dim3(512), 0, st, w); else hipLaunchKernelGGL((wide_l1_bwd16_kernel<false, false>), grid, dim3(512), 0, st, w); }
+  if (w.rows) { if (fn) wide16_l1_bwd_one<true, true>(w, grid, st); else wide16_l1_bwd_one<false, true>(w, grid, st); }
+  else { if (fn) wide16_l1_bwd_one<true, false>(w, grid, st); else wide16_l1_bwd_one<false, false>(w, grid, st); }
   return MAPPO_OK;
 }
 #endif

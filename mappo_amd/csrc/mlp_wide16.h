@@ -277,16 +277,19 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
 // their tiles independently (one wave's row loads and statistics run under the other waves' MFMAs).  Streaming the chunks
 // through a double buffer (wide16_layer1, kept for the rollout kernel where a workgroup sees too few tiles to amortise the
 // staging) left every chunk waiting for an L2 round trip behind a workgroup barrier: 4 us per chunk against 2 us of MFMA.
-template <int NCH>
+// FULL (in_dim == 64 NCH): every chunk is whole and 16-byte granular, so the tile loop is ONE basic block — no per-chunk branches
+// on the row length and no branch around the refill (the last tile reloads itself): hipcc then issues a chunk's LDS reads under the
+// MFMAs of the chunk before (with the branches every 32 MFMAs started behind an exposed LDS round trip).
+template <int NCH, bool FULL>
 __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = p.D;
   const bool fnorm = p.fn_w >= 0;
-  const bool al4 = (D & 3) == 0;
+  const bool al4 = FULL || (D & 3) == 0;
   const float inv_D = 1.0f / (float)D;
-  const int c_last = (D + 63) / 64 - 1;
+  const int c_last = FULL ? NCH - 1 : (D + 63) / 64 - 1;
   // W1' in LDS in FRAGMENT order: the 16 x 16 block (bo, kb) — rows 16 bo + n, columns 16 kb + 4 q + t — is 256 consecutive
   // floats with lane (n, q)'s four values at float offset 4 * lane, so an A operand read is base + 16 * lane bytes and every
   // 16-lane group of the ds_read_b128 covers the 64 banks once.  (The row-major copy with stride 64 nch + 4 of round 2 put lanes
@@ -321,7 +324,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   auto load_rows = [&](const float *xr, int c) {              // raw (ld4_row_fix is applied to the last chunk when the tile starts)
     int ql = q;
     asm volatile("" : "+v"(ql));                              // (offsets recomputed per call, not kept as address pairs)
-    if (c < c_last) {
+    if (FULL || c < c_last) {
       const float *xc = xr + 4 * ql;
 #pragma unroll
       for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4u(xc + 64 * c + 16 * j4);
@@ -349,12 +352,14 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
     const float *xr_next = row_ptr(has_next ? next : tile);
     int ql = q;
     asm volatile("" : "+v"(ql));
+    if constexpr (!FULL) {
 #pragma unroll
-    for (int c = 0; c < NCH; ++c)
-      if (c == c_last) {
+      for (int c = 0; c < NCH; ++c)
+        if (c == c_last) {
 #pragma unroll
-        for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_fix(xq[c][j4], 64 * c + 16 * j4 + 4 * ql, D, al4);
-      }
+          for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_fix(xq[c][j4], 64 * c + 16 * j4 + 4 * ql, D, al4);
+        }
+    }
     // ---- LayerNorm statistics over the D inputs (exact two-pass on the registers); the inputs become x - mean ----
     float mean = 0.f, rstd = 1.f;
     if (fnorm) {
@@ -368,7 +373,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
       f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        if (c < c_last) {
+        if (FULL || c < c_last) {
 #pragma unroll
           for (int j4 = 0; j4 < 4; ++j4) { const f32x4 d = xq[c][j4] - mean4; xq[c][j4] = d; v4 += d * d; }
         } else if (c == c_last) {
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
     for (int bo = 0; bo < 4; ++bo) acc[bo] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      if (c <= c_last) {
+      if (FULL || c <= c_last) {
         const float *Wc = sW + (4 * c * 64 + lane) * 4;          // block (bo, kb = 4 c + jj) at (bo KB + kb) * 256
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
 #pragma unroll
             for (int bo = 0; bo < 4; ++bo) acc[bo] = WIDE_MFMA(a[bo][t], xq[c][jj][t], acc[bo]);
         }
-        if (has_next) load_rows(xr_next, c);                   // these 16 registers are free: the next tile's columns
+        if (FULL || has_next) load_rows(xr_next, c);           // these 16 registers are free: the next tile's columns
       }
     }
     const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
@@ -749,7 +754,13 @@ struct WideBwdOps {
 // the 64 accumulators in different registers per copy and shuffle / spill them at the joins): feature norm and row gather are
 // template parameters chosen by the host; the row-end chunk and the one partial tile of a batch are small uniform branches
 // around the per-element fix-ups only.
-template <bool FNORM, bool GATHER>
+// FULL (in_dim a multiple of 64: no row-end chunk): the loop over a wave's FULL tiles is ONE basic block — three operand sets in
+// rotation, every fetch unconditional (tile indices clamped to the batch, a repeat's products scaled by 0), the chunk-0 wave's bias
+// sums by a 0/1 factor instead of a branch — and the batch's one partial tile runs after it.  With the conditional fetches of the
+// general loop hipcc's wait-count insertion loses track of the rotation at the branch joins and puts s_waitcnt vmcnt(0) in front
+// of a set's products: each compute then also waits for the prefetch issued just before it (58 % of the wave cycles waiting,
+// profiles/r03/d_wide_l1_kernels_sq_pmc.txt); in the single block it counts the outstanding loads exactly (vmcnt(20)).
+template <bool FNORM, bool GATHER, bool FULL>
 __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) {
   __shared__ float sDb[8][HID];
   const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4;
@@ -839,7 +850,88 @@ __global__ __launch_bounds__(512, 2) void wide_l1_bwd16_kernel(WideBwd16Args p) 
       for (int bf = 0; bf < 4; ++bf) db[bf] += (o.a[bf][0] + o.a[bf][1]) + (o.a[bf][2] + o.a[bf][3]);
     }
   };
-  if (active) {
+  if (FULL && active) {
+    const float dbw = chunk == 0 ? 1.f : 0.f;
+    const int64_t cnt = tile0 < n_full ? (n_full - 1 - tile0) / stride + 1 : 0;      // this wave's full tiles
+    const int64_t t_hi = n_full - 1;
+    auto fetch_f = [&](WideBwdOps &o, int64_t tile, const int (&ridx)[4]) __attribute__((always_inline)) {
+      const float *dzt = dz + tile * 1024 + n * 16 + 4 * q;
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf) o.a[bf] = ld4(dzt + 256 * bf);
+      o.mean = ld4(st_mean + tile * 16 + 4 * q);
+      o.rstd = ld4(st_rstd + tile * 16 + 4 * q);
+      if (GATHER) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.b[j] = ld4u(p.x + (int64_t)ridx[j] * p.D + kcol);
+      } else {
+#ifdef WIDE_EXP_ROW0
+        const float *xr = p.x + (0 * tile * 16 + 4 * q) * p.D + kcol;
+#else
+        const float *xr = p.x + (tile * 16 + 4 * q) * p.D + kcol;
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o.b[j] = ld4u(xr + (int64_t)j * p.D);
+      }
+    };
+    auto rows_f = [&](int (&ridx)[4], int64_t tile) __attribute__((always_inline)) {
+      if (GATHER) {
+        const int64_t s0 = tile * 16 + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ridx[j] = p.rows[s0 + j];
+      }
+    };
+    auto compute_f = [&](WideBwdOps &o, float valid) __attribute__((always_inline)) {
+      const f32x4 v4 = {valid, valid, valid, valid};
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf) o.a[bf] *= v4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 xh = o.b[j];
+        if (fnorm) {
+          const f32x4 m4 = {o.mean[j], o.mean[j], o.mean[j], o.mean[j]}, r4 = {o.rstd[j], o.rstd[j], o.rstd[j], o.rstd[j]};
+          xh = (xh - m4) * r4;
+        }
+#pragma unroll
+        for (int bf = 0; bf < 4; ++bf)
+#pragma unroll
+          for (int bk = 0; bk < 4; ++bk) G[bf][bk] = WIDE_MFMA(o.a[bf][j], xh[bk], G[bf][bk]);
+      }
+#pragma unroll
+      for (int bf = 0; bf < 4; ++bf) db[bf] += dbw * ((o.a[bf][0] + o.a[bf][1]) + (o.a[bf][2] + o.a[bf][3]));
+    };
+    if (cnt > 0) {
+      auto tl = [&](int64_t k) { return min(tile0 + k * stride, t_hi); };
+      WideBwdOps o0, o1, o2;
+      int r0[4] = {0, 0, 0, 0}, r1[4] = {0, 0, 0, 0}, r2[4] = {0, 0, 0, 0};
+      rows_f(r0, tl(0)); rows_f(r1, tl(1)); rows_f(r2, tl(2));
+      fetch_f(o0, tl(0), r0);
+      fetch_f(o1, tl(1), r1);
+      // (sched_barrier: hipcc's scheduler otherwise sinks a set's loads down to their first use two tiles later — fewer live
+      // registers, and every product behind an exposed memory round trip)
+      for (int64_t k = 0; k < cnt; k += 3) {
+        fetch_f(o2, tl(k + 2), r2); rows_f(r0, tl(k + 3));
+        __builtin_amdgcn_sched_barrier(0);
+        compute_f(o0, 1.f);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_f(o0, tl(k + 3), r0); rows_f(r1, tl(k + 4));
+        __builtin_amdgcn_sched_barrier(0);
+        compute_f(o1, k + 1 < cnt ? 1.f : 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch_f(o1, tl(k + 4), r1); rows_f(r2, tl(k + 5));
+        __builtin_amdgcn_sched_barrier(0);
+        compute_f(o2, k + 2 < cnt ? 1.f : 0.f);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // the partial tile (at most one per batch, owned by one tile group)
+    if (n_tiles > n_full && n_full >= tile0 && (n_full - tile0) % stride == 0) {
+      WideBwdOps o;
+      int r[4] = {0, 0, 0, 0};
+      if (GATHER) fetch_rows(r, n_full);
+      fetch(o, n_full, r);
+      compute(o, n_full);
+    }
+  } else if (active) {
     // three operand sets: the loads of a tile are issued two tiles (~2 x 1.2 us of MFMA) before its products; with a row gather
     // the indices are fetched one tile further ahead still, so that the x loads never wait for them
     int64_t tile = tile0;
