@@ -221,36 +221,48 @@ struct Tail16Acc {                                                // one wave's 
     }
   }
 };
-struct Tail16In { float f0, f1, f2, f3; uint32_t dead; };         // a row's loss inputs (requested early, used late)
+// A row's loss inputs: requested early, used late.  NOTHING here may be computed from a loaded value: an instruction on a value still
+// in flight puts the wait for it — and, the counter being in order, for every load issued before it — right where the loads are
+// issued (the availability mask was built here at first: s_waitcnt vmcnt(0) at the top of every step).  Row indices stay the raw
+// 32-bit values for the same reason (the caller widens them a step later).
+template <int NBH>
+struct Tail16In { float f0, f1, f2, f3; float av[NBH][4]; };
 struct Tail16Lds { const float *rn_g, *rn_b, *wh, *bh; float *Uy, *Udl; };
 
 template <int HEAD, int NBH>
-__device__ __forceinline__ Tail16In tail16_load(const Gru16Args &p, int64_t brow, int q, int A) {
-  Tail16In r;
-  r.f3 = 0.f; r.dead = 0u;
+__device__ __forceinline__ Tail16In<NBH> tail16_load(const Gru16Args &p, int64_t brow, int q, int A) {
+  Tail16In<NBH> r;
+  r.f3 = 0.f;
   if constexpr (HEAD == 1) {
     r.f0 = p.actions[brow]; r.f1 = p.old_logp[brow]; r.f2 = p.adv[brow]; r.f3 = p.active[brow];
-    if (p.avail) {
-      const float *av = p.avail + brow * A;
-      float v[NBH][4];
+    // unconditional (a branch around these loads ends in copies of the loaded registers at its join — a wait again): without
+    // available_actions the four dwords are re-reads of active[brow], never looked at
+    const float *av = p.avail ? p.avail + brow * A : p.active + brow;
+    const int amax = p.avail ? A - 1 : 0;
 #pragma unroll
-      for (int bo = 0; bo < NBH; ++bo)
+    for (int bo = 0; bo < NBH; ++bo)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[bo][i] = av[min(16 * bo + 4 * q + i, A - 1)];
-#pragma unroll
-      for (int bo = 0; bo < NBH; ++bo)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) r.dead |= ((16 * bo + 4 * q + i < A && v[bo][i] == 0.f) ? 1u : 0u) << (4 * bo + i);
-    }
+      for (int i = 0; i < 4; ++i) r.av[bo][i] = av[min(16 * bo + 4 * q + i, amax)];
   } else {
     r.f0 = p.v_old[brow]; r.f1 = p.returns[brow]; r.f2 = p.active[brow];
   }
   return r;
 }
+template <int NBH>
+__device__ __forceinline__ uint32_t tail16_dead(const Gru16Args &p, const Tail16In<NBH> &in, int q, int A) {
+  uint32_t dead = 0u;
+  if (p.avail) {
+#pragma unroll
+    for (int bo = 0; bo < NBH; ++bo)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dead |= ((16 * bo + 4 * q + i < A && in.av[bo][i] == 0.f) ? 1u : 0u) << (4 * bo + i);
+  }
+  return dead;
+}
 
 // h: the wave's tile of h_t (accumulator layout); d <- d h_t without the recurrent term
 template <int HEAD, int NBH>
-__device__ __forceinline__ void tail16_step(const Gru16Args &p, const Tail16Lds &L, const LossScales &ls, const Tail16In &in, const f32x4 (&h)[4],
+__device__ __forceinline__ void tail16_step(const Gru16Args &p, const Tail16Lds &L, const LossScales &ls, const Tail16In<NBH> &in, const f32x4 (&h)[4],
                                             bool ok, int A, int lane, Tail16Acc<HEAD, NBH> &acc, f32x4 (&d)[4]) {
   constexpr int DLS = NBH == 1 ? 20 : 36;
   const int n = lane & 15, q = lane >> 4;
@@ -289,7 +301,7 @@ __device__ __forceinline__ void tail16_step(const Gru16Args &p, const Tail16Lds 
 #pragma unroll
         for (int bo = 0; bo < NBH; ++bo) zl[bo] = mfma16(a[bo][i], y[b][i], zl[bo]);
     }
-    actor_loss_q16<NBH>(zl, A, q, in.dead, (int)in.f0, in.f1, in.f2, in.f3, ok, p.cfg, ls.scale_pi, acc.lacc);
+    actor_loss_q16<NBH>(zl, A, q, tail16_dead<NBH>(p, in, q, A), (int)in.f0, in.f1, in.f2, in.f3, ok, p.cfg, ls.scale_pi, acc.lacc);
 #pragma unroll
     for (int bo = 0; bo < NBH; ++bo) st4(Udl + n * DLS + 16 * bo + 4 * q, zl[bo]);
     wave_lds_sync();
@@ -471,16 +483,19 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
     for (int b = 0; b < 4; ++b) h[b] = ld4(p.h0 + hrow * HID + 16 * b + 4 * q);
     // the reset mask gates the first MFMA of a step, behind a two-deep dependent load (rows -> masks): the row index runs two steps
     // ahead and the mask one step ahead, so a lone wave of a SIMD (small batches) does not wait for either
-    auto row_of = [&](int t) -> int64_t {
+    auto row_of = [&](int t) -> int {                           // raw: see Tail16In
       const int64_t col = (int64_t)min(t, p.L - 1) * p.Nc + cc;
-      return p.rows ? (int64_t)p.rows[col] : col;
+      int r = (int)col;
+      if (p.rows) r = p.rows[col];
+      return r;
     };
-    int64_t brow = row_of(0), brow1 = row_of(1);
-    float mk = p.masks[brow];
+    int r0 = row_of(0), r1 = row_of(1);
+    float mk = p.masks[r0];
     for (int t = 0; t < p.L; ++t) {
       const int64_t col = (int64_t)t * p.Nc + cc;
-      const int64_t brow2 = row_of(t + 2);
-      const float mk1 = p.masks[brow1];
+      const int r2 = row_of(t + 2);
+      const float mk1 = p.masks[r1];
+      const int64_t brow = r0;
       // ---- this step's inputs: everything is requested before the first use ----
       f32x4 x[4];
       if constexpr (XBLK) {
@@ -493,7 +508,7 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
 #pragma unroll
           for (int i = 0; i < 4; ++i) x[b][i] = p.x[(int64_t)(16 * b + 4 * q + i) * B + col];
       }
-      const Tail16In in = tail16_load<HEAD, NBH>(p, brow, q, A);
+      const Tail16In<NBH> in = tail16_load<HEAD, NBH>(p, brow, q, A);
       const float mk0 = ok ? mk : 0.f;
       f32x4 hm[4];
 #pragma unroll
@@ -535,7 +550,7 @@ __device__ __forceinline__ void gru16_fwd_body(const Gru16Args &p, float *lds, c
       tail16_step<HEAD, NBH>(p, TL, ls, in, h, ok, A, lane, acc, d);
 #pragma unroll
       for (int b = 0; b < 4; ++b) st4(sb + C_DH * CS + b * 256, d[b]);
-      brow = brow1; brow1 = brow2; mk = mk1;
+      r0 = r1; r1 = r2; mk = mk1;
     }
   }
   // ---- workgroup reduction -> slab row `bid`, loss partials ----
@@ -585,12 +600,22 @@ __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, c
       }
     };
     load6(pf, p.scratch + ((int64_t)((p.L - 1) * n_ct + tile) * 4) * 256 + lane * 4);
+    // reset mask of a step: behind a two-deep gather (rows -> masks).  The row index runs two steps ahead and the mask one, both
+    // untouched until the step that uses them (raw 32-bit index: see Tail16In) — read in place, the chain was a memory round trip
+    // in front of every step's 24 loads.
+    auto row_of = [&](int t) -> int {
+      const int64_t col = (int64_t)max(t, 0) * p.Nc + cc;
+      int r = (int)col;
+      if (p.rows) r = p.rows[col];
+      return r;
+    };
+    int r1 = row_of(p.L - 2);
+    float mkc = p.masks[row_of(p.L - 1)];
     for (int t = p.L - 1; t >= 0; --t) {
       // (compiler fence: without it hipcc hoists the NEXT step's 24 loads above this step's MFMA phase — 96 more live registers,
       // 124 of them spilled; the partner wave of the SIMD covers the load latency instead)
       asm volatile("" ::: "memory");
       const int64_t col = (int64_t)t * p.Nc + cc;
-      const int64_t brow = p.rows ? (int64_t)p.rows[col] : col;
       float *sb = p.scratch + ((int64_t)(t * n_ct + tile) * 4) * 256 + lane * 4;
       f32x4 dh[4], hm[4], gr[4], gz[4], gn[4], ghn[4];
       if constexpr (PRE) {
@@ -608,8 +633,9 @@ __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, c
           hm[b] = ld4(sb + C_HM * CS + b * 256);
         }
       }
-      float mk = p.masks[brow];
-      mk = ok ? mk : 0.f;
+      const int r2 = row_of(t - 2);
+      const float mk1 = p.masks[r1];
+      const float mk = ok ? mkc : 0.f;
       // d gates, IN PLACE (gr <- d pre_r, hm <- d pre_z, gn <- d pre_n = d gi_n, ghn <- d gh_n; dh <- d h_t + carry): the register
       // file holds exactly the six loaded vectors.  Dead sequences: d h = 0 and carry = 0, so every product below is 0.
 #pragma unroll
@@ -665,6 +691,7 @@ __device__ __forceinline__ void gru16_bwd_body(const Gru16Args &p, float *lds, c
 #pragma unroll
         for (int i = 0; i < 4; ++i) carry[b][i] = (dhm[b][i] + dh[b][i] * gz[b][i]) * mk;
       }
+      r1 = r2; mkc = mk1;
     }
   }
 }
@@ -721,9 +748,11 @@ __global__ __launch_bounds__(4 * WAVE) void gru16s_fwd_kernel(Gru16Args p) {
   const int64_t hrow = p.h0_rows ? (int64_t)p.h0_rows[cc] : (int64_t)cc;
   __syncthreads();                                                // the previous tile's last reads of ex[] are done
   st4(&ex[0][j * 256 + lane * 4], ld4(p.h0 + hrow * HID + fo));
-  auto row_of = [&](int t) -> int64_t {
+  auto row_of = [&](int t) -> int {                             // raw: see Tail16In
     const int64_t col = (int64_t)min(t, p.L - 1) * p.Nc + cc;
-    return p.rows ? (int64_t)p.rows[col] : col;
+    int r = (int)col;
+    if (p.rows) r = p.rows[col];
+    return r;
   };
   auto load_x = [&](f32x4 (&x)[4], int t) {
     const int tt = min(t, p.L - 1);
@@ -739,13 +768,13 @@ __global__ __launch_bounds__(4 * WAVE) void gru16s_fwd_kernel(Gru16Args p) {
         for (int i = 0; i < 4; ++i) x[b][i] = p.x[(int64_t)(16 * b + 4 * q + i) * B + col];
     }
   };
-  int64_t brow1 = row_of(1);
+  int r1 = row_of(1);
   float mk = p.masks[row_of(0)];
   f32x4 x[4];
   load_x(x, 0);
   for (int t = 0; t < p.L; ++t) {
-    const int64_t brow2 = row_of(t + 2);
-    const float mk1 = p.masks[brow1];
+    const int r2 = row_of(t + 2);
+    const float mk1 = p.masks[r1];
     // input-side products first: they do not wait for the other waves' h_{t-1}
     f32x4 ar = b_r, az = b_z, ain = b_in, ahn = b_hn;
 #pragma unroll
@@ -789,7 +818,7 @@ __global__ __launch_bounds__(4 * WAVE) void gru16s_fwd_kernel(Gru16Args p) {
     st4(sb + C_N * CS, nn);
     st4(sb + C_GHN * CS, ahn);
     st4(sb + C_DH * CS, hn);                                      // h_t for gru16_head_kernel
-    brow1 = brow2; mk = mk1;
+    r1 = r2; mk = mk1;
   }
   }
 }
@@ -838,12 +867,14 @@ __global__ __launch_bounds__(4 * WAVE) void gru16_head_kernel(Gru16Args p) {
   const int n_ct = (p.Nc + 15) >> 4, n_rt = p.L * n_ct;
   const int64_t CS = (int64_t)p.L * n_ct * 1024;
   const int stride = gridDim.x * M::NW;
-  auto brow_of = [&](int rt) -> int64_t {                         // (clamped: the tile after a wave's last is a repeat, discarded)
+  auto brow_of = [&](int rt) -> int {                             // (clamped: the tile after a wave's last is a repeat, discarded; raw: see Tail16In)
     const int r = min(rt, n_rt - 1), t = r / n_ct, c = (r - t * n_ct) * 16 + n;
     const int64_t col = (int64_t)t * p.Nc + (c < p.Nc ? c : 0);
-    return p.rows ? (int64_t)p.rows[col] : col;
+    int b = (int)col;
+    if (p.rows) b = p.rows[col];
+    return b;
   };
-  auto load_tile = [&](f32x4 (&h)[4], Tail16In &in, int rt, int64_t brow) {
+  auto load_tile = [&](f32x4 (&h)[4], Tail16In<NBH> &in, int rt, int64_t brow) {
     const float *sb = p.scratch + C_DH * CS + (int64_t)min(rt, n_rt - 1) * 1024 + lane * 4;
 #pragma unroll
     for (int b = 0; b < 4; ++b) h[b] = ld4(sb + b * 256);
@@ -852,11 +883,11 @@ __global__ __launch_bounds__(4 * WAVE) void gru16_head_kernel(Gru16Args p) {
   // a row's inputs sit behind a two-deep gather (rows -> loss inputs): row indices run two tiles ahead, the inputs one
   int rt = blockIdx.x * M::NW + wave;
   f32x4 h[4], hn[4];
-  Tail16In in, inn;
-  int64_t brow1 = brow_of(rt + stride);
+  Tail16In<NBH> in, inn;
+  int brow1 = brow_of(rt + stride);
   load_tile(h, in, rt, brow_of(rt));
   for (; rt < n_rt; rt += stride) {
-    const int64_t brow2 = brow_of(rt + 2 * stride);
+    const int brow2 = brow_of(rt + 2 * stride);
     load_tile(hn, inn, rt + stride, brow1);
     const int t = rt / n_ct, tile = rt - t * n_ct;
     const bool ok = tile * 16 + n < p.Nc;
@@ -899,18 +930,25 @@ __global__ __launch_bounds__(4 * WAVE) void gru16s_bwd_kernel(Gru16Args p) {
   f32x4 carry = {0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   struct Step { f32x4 dh, z, nn, r, ghn, hm; float mk; };
-  auto load_step = [&](Step &s, int t) {
+  auto row_of = [&](int t) -> int {                               // raw 32-bit row index, used a step after it is loaded (see Tail16In)
+    const int64_t col = (int64_t)max(t, 0) * p.Nc + cc;
+    int r = (int)col;
+    if (p.rows) r = p.rows[col];
+    return r;
+  };
+  auto load_step = [&](Step &s, int t, int row) {
     const int tt = max(t, 0);
     const float *sb = p.scratch + ((int64_t)(tt * n_ct + tile) * 4) * 256 + j * 256 + lane * 4;
     s.dh = ld4(sb + C_DH * CS); s.z = ld4(sb + C_Z * CS); s.nn = ld4(sb + C_N * CS);
     s.r = ld4(sb + C_R * CS); s.ghn = ld4(sb + C_GHN * CS); s.hm = ld4(sb + C_HM * CS);
-    const int64_t col = (int64_t)tt * p.Nc + cc;
-    s.mk = p.masks[p.rows ? (int64_t)p.rows[col] : col];
+    s.mk = p.masks[row];
   };
   Step cur, nxt;
-  load_step(cur, p.L - 1);
+  load_step(cur, p.L - 1, row_of(p.L - 1));
+  int r1 = row_of(p.L - 2);
   for (int t = p.L - 1; t >= 0; --t) {
-    load_step(nxt, t - 1);                                        // own block only (6 KiB per wave): one step ahead
+    const int r2 = row_of(t - 2);                                 // rows two steps ahead, everything else of a step one ahead
+    load_step(nxt, t - 1, r1);                                    // own block only (6 KiB per wave)
     float *sb = p.scratch + ((int64_t)(t * n_ct + tile) * 4) * 256 + j * 256 + lane * 4;
     f32x4 dhh, d_r, d_z, d_n, d_hn;
 #pragma unroll
@@ -964,7 +1002,7 @@ __global__ __launch_bounds__(4 * WAVE) void gru16s_bwd_kernel(Gru16Args p) {
     const float mk = ok ? cur.mk : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) carry[i] = (ca[0][i] + ca[1][i] + dhh[i] * cur.z[i]) * mk;
-    cur = nxt;
+    cur = nxt; r1 = r2;
   }
   }
 }

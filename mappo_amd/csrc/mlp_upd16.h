@@ -679,13 +679,12 @@ __device__ __forceinline__ void update16_body(const Upd16Args &P, float *lds, co
         f32x4 a[4];
 #pragma unroll
         for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(lds + M::W1 + ((bo * M::NT + tc) * 64 + lane) * 4);
+        // (all four k-steps of a started group: slots beyond C meet zero weights — up to 12 idle MFMAs per tile instead of
+        // a uniform branch per k-step, each of which ended a basic block in front of the next group's LDS reads)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (4 * tc + i < C) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int bo = 0; bo < 4; ++bo) xh[bo] = mfma16(a[bo][i], x0[4 * tc + i], xh[bo]);
-          }
-        }
+          for (int bo = 0; bo < 4; ++bo) xh[bo] = mfma16(a[bo][i], x0[4 * tc + i], xh[bo]);
       }
     }
     }
