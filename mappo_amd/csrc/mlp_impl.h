@@ -1308,6 +1308,9 @@ int wide16_launch_features_dual_r(int ln, dim3 grid, dim3 block, size_t lds_byte
 template <bool R>
 int wide16_launch_rollout_step_r(int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
                                  const Wide16Args &wc, const FwdArgs &c, int nA);
+template <bool R>
+int wide16_launch_rollout_full_r(int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                 const Wide16Args &wc, const FwdArgs &c, int nA, const InsertArgs *ins);
 // split-K variants (one tile per 4-wave workgroup): step-sized batches
 int wide16_launch_forward_sk(int mode, bool relu, int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &w, const FwdArgs &a,
                              const char *who);
@@ -1416,6 +1419,28 @@ int wide16_launch_rollout_step_r(int ln, dim3 grid, size_t lds_bytes, hipStream_
 }
 template int wide16_launch_rollout_step_r<MLP_WIDE_RELU>(int, dim3, size_t, hipStream_t, const Wide16Args &, const FwdArgs &, const Wide16Args &,
                                                          const FwdArgs &, int);
+
+template <bool R, int L, int NCH>
+static int wide16_rollout_full_one(dim3 grid, size_t lds_bytes, hipStream_t st, const WideFullArgs &s) {
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_rollout_full_kernel<R, L, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("rollout_step: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  PROF_LAUNCH(MAPPO_PROF_ACT, (wide_rollout_full_kernel<R, L, NCH>), grid, dim3(512), lds_bytes, st, s);
+  return MAPPO_OK;
+}
+// in_dim of BOTH networks == 64 NCH, NCH 4 or 8 (the caller checks); ins: rewards / masks of the fused insert or NULL
+template <bool R>
+int wide16_launch_rollout_full_r(int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
+                                 const Wide16Args &wc, const FwdArgs &c, int nA, const InsertArgs *ins) {
+  WideFullArgs s = {};
+  s.wa = wa; s.wc = wc; s.a = a; s.c = c; s.nA = nA;
+  if (ins) { s.ins = *ins; s.has_ins = 1; }
+  const bool big = wa.D == 512;
+  if (ln == 0) return big ? wide16_rollout_full_one<R, 0, 8>(grid, lds_bytes, st, s) : wide16_rollout_full_one<R, 0, 4>(grid, lds_bytes, st, s);
+  if (ln == 1) return big ? wide16_rollout_full_one<R, 1, 8>(grid, lds_bytes, st, s) : wide16_rollout_full_one<R, 1, 4>(grid, lds_bytes, st, s);
+  return big ? wide16_rollout_full_one<R, 2, 8>(grid, lds_bytes, st, s) : wide16_rollout_full_one<R, 2, 4>(grid, lds_bytes, st, s);
+}
+template int wide16_launch_rollout_full_r<MLP_WIDE_RELU>(int, dim3, size_t, hipStream_t, const Wide16Args &, const FwdArgs &, const Wide16Args &,
+                                                         const FwdArgs &, int, const InsertArgs *);
 #endif
 
 #ifdef MLP_TU_WIDE_SK
@@ -1860,7 +1885,14 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
   if (actor_desc->in_dim > MAXD) {
     // Wide inputs: the insert is its own (HBM-bound: it moves the rows it copies once in, twice out) launch, the two networks share
     // one (wide_rollout_step_kernel: every CU busy for one chunk-latency chain instead of half the chip for two).
-    if (obs_dst)
+    // in_dim 256 / 512 on both networks and at most two tiles per wave: W1' staged whole, and the insert's row copies ride on the
+    // forward's loads (wide_rollout_full_kernel); MAPPO_WIDE_FULL_STEP=0: the streamed form (A/B)
+    const int64_t nt16_ = (B + 15) / 16;
+    const bool full_step = actor_desc->in_dim == critic_desc->in_dim && (actor_desc->in_dim == 256 || actor_desc->in_dim == 512) &&
+                           nt16_ <= 2 * 8 * (NUM_CU / 2) && !(getenv("MAPPO_WIDE_FULL_STEP") && atoi(getenv("MAPPO_WIDE_FULL_STEP")) == 0);
+    const bool fuse_ins = full_step && obs_dst && actions && !centralized && obs_stride_m == actor_desc->in_dim &&
+                          share_stride_m == critic_desc->in_dim;
+    if (obs_dst && !fuse_ins)
       if (int rci = mappo_insert_mpe(obs, obs_stride_n, obs_stride_m, rewards, rew_stride_n, rew_stride_m, dones, done_stride_n, done_stride_m,
                                      obs_dst, share_dst, rew_dst, mask_dst, (int32_t)(B / M), M, actor_desc->in_dim, centralized, stream))
         return rci;
@@ -1883,6 +1915,23 @@ extern "C" int mappo_rollout_step(const float *actor_params, const mappo_net_des
     const int nA = actions ? nb : 0;
     const dim3 grid((unsigned)(nA + nb));
     const size_t lb = lba > lbc ? lba : lbc;
+    if (full_step) {
+      const size_t lw = sizeof(float) * ((size_t)HID * actor_desc->in_dim + HID);      // W1' whole + folded bias; the tail's map reuses the space
+      const size_t lf = lw > lb ? lw : lb;
+      MAPPO_REQUIRE(lf <= 159 * 1024, "rollout_step: needs %zu B of LDS", lf);
+      InsertArgs ins = {};
+      if (fuse_ins) {
+        wa.copy_dst = obs_dst; wc.copy_dst = share_dst;
+        ins.rew = rewards; ins.rew_sn = rew_stride_n; ins.rew_sm = rew_stride_m; ins.done = dones; ins.done_sn = done_stride_n;
+        ins.done_sm = done_stride_m; ins.rew_dst = rew_dst; ins.mask_dst = mask_dst; ins.N = (int)(B / M); ins.M = M;
+      }
+      const int rcf = actor_desc->use_relu
+          ? wide16_launch_rollout_full_r<true>(actor_desc->layer_N, grid, lf, as_stream(stream), wa, a, wc, c, nA, fuse_ins ? &ins : nullptr)
+          : wide16_launch_rollout_full_r<false>(actor_desc->layer_N, grid, lf, as_stream(stream), wa, a, wc, c, nA, fuse_ins ? &ins : nullptr);
+      if (rcf) return rcf;
+      MAPPO_CHECK_LAUNCH("rollout_step");
+      return MAPPO_OK;
+    }
     const int rcw = actor_desc->use_relu ? wide16_launch_rollout_step_r<true>(actor_desc->layer_N, grid, lb, as_stream(stream), wa, a, wc, c, nA)
                                          : wide16_launch_rollout_step_r<false>(actor_desc->layer_N, grid, lb, as_stream(stream), wa, a, wc, c, nA);
     if (rcw) return rcw;

@@ -14,6 +14,7 @@
 //     fetched (global -> registers) under the 64 MFMAs of chunk c and stored before the single barrier per chunk;
 //   * output z1 [B][64] row-major (the accumulator layout gives each lane 4 x 16 contiguous bytes).
 #pragma once
+#include "insert_core.h"
 #include "mlp_wide16_args.h"
 
 // experiment hooks (scripts/exp_build.py): -DWIDE_EXP_NOMFMA replaces the matrix instruction by one add (what is left is the
@@ -515,6 +516,137 @@ __global__ __launch_bounds__(512, 2) void wide_rollout_step_kernel(WideStepArgs 
   __shared__ __align__(16) float sB[HID];
   if ((int)blockIdx.x < s.nA) wide_forward16_body<RELU, LN, 1, 8, NCH>(s.wa, s.a, lds, sW, sB, blockIdx.x, s.nA);
   else wide_forward16_body<RELU, LN, 0, 8, NCH>(s.wc, s.c, lds, sW, sB, (int)blockIdx.x - s.nA, (int)gridDim.x - s.nA);
+}
+
+// The same step when in_dim is 256 or 512 and a wave sees at most two tiles (BASELINE configs[4]: 1 024 tiles per network on 128
+// workgroups each): W1' is staged WHOLE, in fragment order, behind ONE memory latency (the streamed form above pays a chunk
+// fetch + barrier eight times: 48 us per step), the tile's rows — requested before the staging — feed the branch-free MFMA loop of
+// wide_l1_fwd16_kernel<NCH, true>, and z1 waits in registers while the workgroup swaps W1' for the tail's weights (the two do not
+// fit the LDS together).  The rows a network loads are also stored to its buffer slot (copy_dst): the rollout insert's obs /
+// share_obs copies — 34 us of their own at configs[4], an element-wise kernel moving each row once in and twice out — ride on
+// loads the forward does anyway; rewards and masks are a few elements per workgroup at the end.
+struct WideFullArgs { Wide16Args wa, wc; FwdArgs a, c; int nA; InsertArgs ins; int has_ins; };
+
+template <bool RELU, int LN, int MODE, int NCH>
+__device__ __forceinline__ void wide_full_body(const Wide16Args &w, const FwdArgs &p, float *lds, const int bid, const int nb) {
+  constexpr int D = 64 * NCH, KB = 4 * NCH;
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool fnorm = w.fn_w >= 0;
+  const float inv_D = 1.0f / (float)D;
+  float *sW = lds, *sB = lds + HID * D;
+  const int64_t n_tiles = (w.B + 15) / 16, stride = (int64_t)nb * 8;
+  const int64_t tile0 = (int64_t)bid * 8 + wave;
+  const bool has[2] = {tile0 < n_tiles, tile0 + stride < n_tiles};
+  auto src_of = [&](int64_t tile) {
+    const int64_t i = tile * 16 + n, row = i < w.B ? i : 0;
+    return w.x + (w.x_M ? (row / w.x_M) * w.x_sn + (row % w.x_M) * w.x_sm : row * D);
+  };
+  f32x4 xq[NCH][4];
+  auto load_rows = [&](const float *xr, int c) {
+    int ql = q;
+    asm volatile("" : "+v"(ql));
+    const float *xc = xr + 4 * ql + 64 * c;
+#pragma unroll
+    for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4u(xc + 16 * j4);
+  };
+  {
+    const float *xr = src_of(has[0] ? tile0 : 0);             // requested before the staging: in flight under it
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load_rows(xr, c);
+  }
+  {
+    constexpr int nv = 4 * KB;
+    for (int e = tid; e < HID * nv; e += blockDim.x) {
+      const int f = e / nv, g4 = e - f * nv, k = 4 * g4;
+      f32x4 wv = ld4u(w.params + w.w1 + (size_t)f * D + k);
+      if (fnorm) wv *= ld4u(w.params + w.fn_w + k);
+      st4(sW + (((f >> 4) * KB + (g4 >> 2)) * 64 + (g4 & 3) * 16 + (f & 15)) * 4, wv);
+    }
+    wide16_fold_bias<8>(w, sB);
+  }
+  __syncthreads();
+  f32x4 z[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) z[t][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (has[t]) {                                              // (wave-uniform; the block below is straight-line code)
+      const int64_t tile = tile0 + t * stride, i = tile * 16 + n;
+      const bool ok = i < w.B;
+      if (w.copy_dst && ok) {
+        float *dst = w.copy_dst + i * D + 4 * q;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) st4(dst + 64 * c + 16 * j4, xq[c][j4]);
+      }
+      float rstd = 1.f;
+      if (fnorm) {
+        f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) s4 += xq[c][j4];
+        const float mean = quad_sum16((s4[0] + s4[1]) + (s4[2] + s4[3])) * inv_D;
+        const f32x4 mean4 = {mean, mean, mean, mean};
+        f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+          for (int j4 = 0; j4 < 4; ++j4) { const f32x4 d = xq[c][j4] - mean4; xq[c][j4] = d; v4 += d * d; }
+        rstd = 1.0f / sqrtf(quad_sum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * inv_D + LN_EPS);
+      }
+      const float *xr_next = src_of(has[1] ? tile0 + stride : tile0);
+      f32x4 acc[4];
+#pragma unroll
+      for (int bo = 0; bo < 4; ++bo) acc[bo] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float *Wc = sW + (4 * c * 64 + lane) * 4;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          f32x4 a[4];
+#pragma unroll
+          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + (bo * KB + jj) * 256);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) acc[bo] = WIDE_MFMA(a[bo][r], xq[c][jj][r], acc[bo]);
+        }
+        if (t == 0) load_rows(xr_next, c);                     // the second tile's columns (a repeat of the first if there is none)
+      }
+      const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
+#pragma unroll
+      for (int b = 0; b < 4; ++b) z[t][b] = acc[b] * rstd4 + ld4(sB + 16 * b + 4 * q);
+    }
+  }
+  __syncthreads();                                             // every wave is done with W1': the tail's weights take its place
+  stage_tail_1shot<LN>(lds, p.map, p.params, p.off, p.desc);
+  __syncthreads();
+  float *tZ = lds + p.map.tiles + wave * p.map.wave_stride;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+    if (has[t]) {
+      const int64_t i = (tile0 + t * stride) * 16 + n;
+      forward16_tail<RELU, LN, MODE>(p, lds, p.map, z[t], i, i < w.B, n, q, tZ);
+    }
+}
+
+template <bool RELU, int LN, int NCH>
+__global__ __launch_bounds__(512, 2) void wide_rollout_full_kernel(WideFullArgs s) {
+  extern __shared__ __align__(16) float lds[];
+  if ((int)blockIdx.x < s.nA) wide_full_body<RELU, LN, 1, NCH>(s.wa, s.a, lds, blockIdx.x, s.nA);
+  else wide_full_body<RELU, LN, 0, NCH>(s.wc, s.c, lds, (int)blockIdx.x - s.nA, (int)gridDim.x - s.nA);
+  if (s.has_ins) {                                             // rewards / masks of the insert (the row copies rode on the loads above)
+    const InsertArgs &p = s.ins;
+    const int64_t R = (int64_t)p.N * p.M;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < R; e += (int64_t)gridDim.x * blockDim.x) {
+      const int nn = (int)(e / p.M), m = (int)(e - (int64_t)nn * p.M);
+      p.rew_dst[e] = p.rew[nn * p.rew_sn + m * p.rew_sm];
+      p.mask_dst[e] = p.done[nn * p.done_sn + m * p.done_sm] ? 0.f : 1.f;
+    }
+  }
 }
 
 // Trunk features of a recurrent actor AND critic with wide inputs in one launch (rollout step: the two networks read different

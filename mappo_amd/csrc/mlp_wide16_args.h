@@ -13,6 +13,9 @@ struct Wide16Args {
   // x[n * x_sn + m * x_sm] — the env's output read in place (mappo_rollout_step); x_M == 0: contiguous rows x[i * D]
   int x_M;
   int64_t x_sn, x_sm;
+  // wide_rollout_full_kernel only: the rows this network reads are also written, as they are, to copy_dst [B][D] (the rollout insert's
+  // obs / share_obs slot copy, riding on the forward's loads) — or NULL
+  float *copy_dst;
 };
 
 

@@ -711,6 +711,43 @@ def test_rollout_step_fused_matches_separate_launches(ops, centralized):
     same_policy_outputs(act2, lp2, v2)
 
 
+@pytest.mark.parametrize("D,N,M,ins_on", [(512, 37, 7, True), (256, 300, 5, True), (512, 9, 3, False), (512, 1000, 32, True)])
+def test_wide_full_rollout_step_matches_streamed_and_separate_insert(ops, monkeypatch, D, N, M, ins_on):
+    """in_dim 256 / 512 on both networks: mappo_rollout_step takes wide_rollout_full_kernel (W1' staged whole, the insert's row copies
+    riding on the forward's loads).  Against the streamed form (MAPPO_WIDE_FULL_STEP=0: mappo_insert_mpe + wide_rollout_step_kernel):
+    buffer slots bit for bit, values / log-probs to fp32 summation order, actions equal but for CDF-boundary flips.  Sizes: ragged
+    last tile, waves with two tiles (32 000 rows = 2 000 tiles on 1 024 waves per network), no insert."""
+    A = 5
+    R = N * M
+    g = torch.Generator(device="cuda").manual_seed(D + N)
+    obs = torch.randn(N, M, D, device="cuda", generator=g) * 1.5 + 0.3
+    rew = torch.randn(N, 1, device="cuda", generator=g).expand(N, M)
+    dones = torch.rand(N, M, device="cuda", generator=g) > 0.5
+    da, dc = ops.net_desc(D, A), ops.net_desc(D, 1)
+    pa = torch.randn(ops.net_param_count(da), device="cuda", generator=g) * 0.1
+    pc = torch.randn(ops.net_param_count(dc), device="cuda", generator=g) * 0.1
+    out = []
+    for full in ("0", "1"):
+        monkeypatch.setenv("MAPPO_WIDE_FULL_STEP", full)
+        od, sd, rd, md = (torch.full(s_, float("nan"), device="cuda") for s_ in ((N, M, D), (N, M, D), (N, M, 1), (N, M, 1)))
+        act, lp, v = torch.empty(R, device="cuda"), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+        ins = dict(obs_dst=od, share_dst=sd, rewards=(rew, rew.stride(0), rew.stride(1)), dones=(dones, dones.stride(0), dones.stride(1)),
+                   rew_dst=rd, mask_dst=md, centralized=False) if ins_on else None
+        ops.rollout_step(pa, da, pc, dc, (obs, obs.stride(0), obs.stride(1)), (obs, obs.stride(0), obs.stride(1)), M, R,
+                         None, False, 4321, 11, None, act, lp, v, ins)
+        torch.cuda.synchronize()
+        out.append((od, sd, rd, md, act, lp, v))
+    a0, a1 = out
+    if ins_on:
+        for x0, x1 in zip(a0[:4], a1[:4]):
+            np.testing.assert_array_equal(x0.cpu().numpy(), x1.cpu().numpy())
+        np.testing.assert_array_equal(a1[0].cpu().numpy(), obs.cpu().numpy())
+    same = (a0[4] == a1[4]).cpu().numpy()
+    assert same.mean() >= 0.995, same.mean()
+    np.testing.assert_allclose(a1[5].cpu().numpy()[same], a0[5].cpu().numpy()[same], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(a1[6].cpu().numpy(), a0[6].cpu().numpy(), rtol=2e-5, atol=2e-6)
+
+
 def test_reduce_clip_adam_matches_slab_reduce_then_clip_adam(ops):
     """mappo_reduce_clip_adam (2 launches) == mappo_slab_reduce + mappo_clip_adam (4 launches): the reduced gradient bit
     for bit, norms / parameters / moments to fp32 rounding of the norm (its double partial sums associate differently)."""
