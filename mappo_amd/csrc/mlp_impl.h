@@ -1309,6 +1309,8 @@ template <bool R>
 int wide16_launch_rollout_step_r(int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
                                  const Wide16Args &wc, const FwdArgs &c, int nA);
 template <bool R>
+int wide16_launch_features_resident_r(int ln, dim3 grid, hipStream_t st, const Wide16Args &w, const FwdArgs &a);
+template <bool R>
 int wide16_launch_rollout_full_r(int ln, dim3 grid, size_t lds_bytes, hipStream_t st, const Wide16Args &wa, const FwdArgs &a,
                                  const Wide16Args &wc, const FwdArgs &c, int nA, const InsertArgs *ins);
 // split-K variants (one tile per 4-wave workgroup): step-sized batches
@@ -1330,22 +1332,25 @@ int wide16_launch_recurrent_step_dual(bool relu, int ln, size_t lds_bytes, hipSt
 #define WIDE_SK_MAX_TILES 256          // per network: above, the streamed kernels fill the chip
 
 #ifdef MLP_TU_WIDE
-template <int NCH, bool FULL>
+template <int NCH>
 static int wide16_l1_fwd_one(const Wide16Args &w, dim3 grid, size_t lds_bytes, hipStream_t st) {
-  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_fwd16_kernel<NCH, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_l1_fwd16_kernel<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
   if (e_ != hipSuccess) { mappo_set_error("wide_l1_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
-  hipLaunchKernelGGL((wide_l1_fwd16_kernel<NCH, FULL>), grid, dim3(512), lds_bytes, st, w);
+  hipLaunchKernelGGL((wide_l1_fwd16_kernel<NCH>), grid, dim3(512), lds_bytes, st, w);
   return MAPPO_OK;
 }
 int wide16_launch_l1_fwd(const Wide16Args &w, dim3 grid, hipStream_t st) {
-  const int nch = (w.D + 63) / 64;
+  const int nch = (w.D + 63) / 64;                                                    // exact: the row-end chunk is static in the kernel
   const size_t lds_bytes = sizeof(float) * ((size_t)HID * 64 * nch + HID);            // W1' whole (fragment order) + folded bias
-  if (w.D == 512) return wide16_l1_fwd_one<8, true>(w, grid, lds_bytes, st);         // whole chunks: branch-free tile loop
-  if (w.D == 256) return wide16_l1_fwd_one<4, true>(w, grid, lds_bytes, st);
-  if (nch <= 2) return wide16_l1_fwd_one<2, false>(w, grid, lds_bytes, st);
-  if (nch <= 4) return wide16_l1_fwd_one<4, false>(w, grid, lds_bytes, st);
-  if (nch <= 6) return wide16_l1_fwd_one<6, false>(w, grid, lds_bytes, st);
-  return wide16_l1_fwd_one<8, false>(w, grid, lds_bytes, st);
+  switch (nch) {
+    case 2: return wide16_l1_fwd_one<2>(w, grid, lds_bytes, st);
+    case 3: return wide16_l1_fwd_one<3>(w, grid, lds_bytes, st);
+    case 4: return wide16_l1_fwd_one<4>(w, grid, lds_bytes, st);
+    case 5: return wide16_l1_fwd_one<5>(w, grid, lds_bytes, st);
+    case 6: return wide16_l1_fwd_one<6>(w, grid, lds_bytes, st);
+    case 7: return wide16_l1_fwd_one<7>(w, grid, lds_bytes, st);
+    default: return wide16_l1_fwd_one<8>(w, grid, lds_bytes, st);
+  }
 }
 
 #endif
@@ -1419,6 +1424,34 @@ int wide16_launch_rollout_step_r(int ln, dim3 grid, size_t lds_bytes, hipStream_
 }
 template int wide16_launch_rollout_step_r<MLP_WIDE_RELU>(int, dim3, size_t, hipStream_t, const Wide16Args &, const FwdArgs &, const Wide16Args &,
                                                          const FwdArgs &, int);
+
+template <bool R, int L, int NCH>
+static int wide16_features_resident_one(dim3 grid, hipStream_t st, const Wide16Args &w, const FwdArgs &a) {
+  static const hipError_t e_ = hipFuncSetAttribute((const void *)wide_features16_resident_kernel<R, L, NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(159 * 1024));
+  if (e_ != hipSuccess) { mappo_set_error("mlp_features: hipFuncSetAttribute: %s", hipGetErrorString(e_)); (void)hipGetLastError(); return MAPPO_ELAUNCH; }
+  const size_t lds_bytes = sizeof(float) * ((size_t)HID * 64 * NCH + HID + a.map.tiles);
+  if (lds_bytes > 159 * 1024) { mappo_set_error("mlp_features: needs %zu B of LDS", lds_bytes); return MAPPO_EINVAL; }
+  PROF_LAUNCH(MAPPO_PROF_MLP_FWD, (wide_features16_resident_kernel<R, L, NCH>), grid, dim3(512), lds_bytes, st, w, a);
+  return MAPPO_OK;
+}
+template <bool R, int L>
+static int wide16_features_resident_nch(dim3 grid, hipStream_t st, const Wide16Args &w, const FwdArgs &a) {
+  switch ((w.D + 63) / 64) {
+    case 2: return wide16_features_resident_one<R, L, 2>(grid, st, w, a);
+    case 3: return wide16_features_resident_one<R, L, 3>(grid, st, w, a);
+    case 4: return wide16_features_resident_one<R, L, 4>(grid, st, w, a);
+    case 5: return wide16_features_resident_one<R, L, 5>(grid, st, w, a);
+    case 6: return wide16_features_resident_one<R, L, 6>(grid, st, w, a);
+    case 7: return wide16_features_resident_one<R, L, 7>(grid, st, w, a);
+    default: return wide16_features_resident_one<R, L, 8>(grid, st, w, a);
+  }
+}
+// layer_N <= 1 (the caller checks); grid: one workgroup per 8 tiles, at most one per CU
+template <bool R>
+int wide16_launch_features_resident_r(int ln, dim3 grid, hipStream_t st, const Wide16Args &w, const FwdArgs &a) {
+  return ln == 0 ? wide16_features_resident_nch<R, 0>(grid, st, w, a) : wide16_features_resident_nch<R, 1>(grid, st, w, a);
+}
+template int wide16_launch_features_resident_r<MLP_WIDE_RELU>(int, dim3, hipStream_t, const Wide16Args &, const FwdArgs &);
 
 template <bool R, int L, int NCH>
 static int wide16_rollout_full_one(dim3 grid, size_t lds_bytes, hipStream_t st, const WideFullArgs &s) {
@@ -2010,6 +2043,13 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
       if (nt16 <= sk_max && !getenv("MAPPO_WIDE_NO_SK")) {          // step-sized batch: one tile per 4-wave workgroup, split-K
         const int64_t gsk = nt16 < NUM_CU ? nt16 : NUM_CU;          // (512 registers per wave: one workgroup per CU; more tiles are walked)
         if (int rcw = wide16_launch_forward_sk(MODE, a.desc.use_relu != 0, LN, dim3((unsigned)gsk), lb, st, w, a, who)) return rcw;
+        MAPPO_CHECK_LAUNCH(who);
+        return MAPPO_OK;
+      }
+      // trunk features of a training-sized batch: W1' resident (wide_features16_resident_kernel); MAPPO_WIDE_RESIDENT=0: streamed (A/B)
+      if (MODE == 2 && LN <= 1 && nt16 >= 2 * 8 * NUM_CU && !(getenv("MAPPO_WIDE_RESIDENT") && atoi(getenv("MAPPO_WIDE_RESIDENT")) == 0)) {
+        const int rcr = a.desc.use_relu ? wide16_launch_features_resident_r<true>(LN, g2, st, w, a) : wide16_launch_features_resident_r<false>(LN, g2, st, w, a);
+        if (rcr) return rcr;
         MAPPO_CHECK_LAUNCH(who);
         return MAPPO_OK;
       }

@@ -278,29 +278,33 @@ __device__ __forceinline__ void wide16_layer1(const Wide16Args &p, float (*sW)[H
 // their tiles independently (one wave's row loads and statistics run under the other waves' MFMAs).  Streaming the chunks
 // through a double buffer (wide16_layer1, kept for the rollout kernel where a workgroup sees too few tiles to amortise the
 // staging) left every chunk waiting for an L2 round trip behind a workgroup barrier: 4 us per chunk against 2 us of MFMA.
-// FULL (in_dim == 64 NCH): every chunk is whole and 16-byte granular, so the tile loop is ONE basic block — no per-chunk branches
-// on the row length and no branch around the refill (the last tile reloads itself): hipcc then issues a chunk's LDS reads under the
-// MFMAs of the chunk before (with the branches every 32 MFMAs started behind an exposed LDS round trip).
-template <int NCH, bool FULL>
-__global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
-  extern __shared__ __align__(16) float lds[];
+// NCH is EXACT (in_dim in (64 (NCH - 1), 64 NCH]): the chunk that holds the row end is static, so the tile loop is ONE basic block —
+// no per-chunk branches on the row length and no branch around the refill (the last tile reloads itself): hipcc then issues a
+// chunk's LDS reads under the MFMAs of the chunk before (with the branches every 32 MFMAs started behind an exposed LDS round
+// trip: 1280 -> 990 us at 1.6 M x 512).  The row end inside the last chunk is loads clamped into the row plus a fix-up / mask at
+// the top of the tile, skipped (one uniform branch, outside the MFMA loop) when in_dim == 64 NCH.
+// tail(acc, i, ok, mean, rstd): acc = z1 of sample i, bias included (accumulator layout).  pre(): the caller's own staging, before
+// the barrier that publishes W1'.  LDS: [W1' 64 x 64 NCH | b1' 64 | caller's].
+template <int NCH, class Pre, class Tail>
+__device__ __forceinline__ void wide_l1_resident_body(const Wide16Args &p, float *lds, Pre &&pre, Tail &&tail) {
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = p.D;
   const bool fnorm = p.fn_w >= 0;
-  const bool al4 = FULL || (D & 3) == 0;
+  const bool al4 = (D & 3) == 0;
+  const bool full = D == 64 * NCH;
   const float inv_D = 1.0f / (float)D;
-  const int c_last = FULL ? NCH - 1 : (D + 63) / 64 - 1;
+  constexpr int c_last = NCH - 1;
   // W1' in LDS in FRAGMENT order: the 16 x 16 block (bo, kb) — rows 16 bo + n, columns 16 kb + 4 q + t — is 256 consecutive
   // floats with lane (n, q)'s four values at float offset 4 * lane, so an A operand read is base + 16 * lane bytes and every
   // 16-lane group of the ds_read_b128 covers the 64 banks once.  (The row-major copy with stride 64 nch + 4 of round 2 put lanes
   // (11, q) and (12, q - 1) of a group on one bank quad: SQ_LDS_BANK_CONFLICT was 49 % of SQ_LDS_IDX_ACTIVE — one conflict cycle
   // per MFMA, profiles/r02/d_wide_l1_kernels_sq_pmc.txt.)
-  const int KB = 4 * (c_last + 1);                              // 16-column blocks per row
+  constexpr int KB = 4 * NCH;                                   // 16-column blocks per row
   float *sW = lds, *sB = lds + HID * 16 * KB;
   // ---- stage W1' = W1 gamma0 (zeros beyond the row) and the folded bias ----
   {
-    const int nv = 4 * KB;                                      // 16-byte groups per row
+    constexpr int nv = 4 * KB;                                  // 16-byte groups per row
     for (int e = tid; e < HID * nv; e += blockDim.x) {
       const int f = e / nv, g4 = e - f * nv, k = 4 * g4;
       f32x4 w = ld4_row(p.params + p.w1 + (size_t)f * D, k, D, al4);
@@ -308,6 +312,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
       st4(sW + (((f >> 4) * KB + (g4 >> 2)) * 64 + (g4 & 3) * 16 + (f & 15)) * 4, w);
     }
     wide16_fold_bias<8>(p, sB);
+    pre();
   }
   __syncthreads();
 
@@ -325,11 +330,11 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   auto load_rows = [&](const float *xr, int c) {              // raw (ld4_row_fix is applied to the last chunk when the tile starts)
     int ql = q;
     asm volatile("" : "+v"(ql));                              // (offsets recomputed per call, not kept as address pairs)
-    if (FULL || c < c_last) {
+    if (c < c_last) {
       const float *xc = xr + 4 * ql;
 #pragma unroll
       for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4u(xc + 64 * c + 16 * j4);
-    } else if (c == c_last) {
+    } else {
 #pragma unroll
       for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_raw(xr, 64 * c + 16 * j4 + 4 * ql, D);
     }
@@ -339,11 +344,7 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
   {
     const float *xr = row_ptr(tile);
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-#pragma unroll
-      for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = f32x4{0.f, 0.f, 0.f, 0.f};     // chunks beyond the row stay zero
-      load_rows(xr, c);
-    }
+    for (int c = 0; c < NCH; ++c) load_rows(xr, c);
   }
   for (;;) {
     const int64_t i = tile * 16 + n;
@@ -353,13 +354,9 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
     const float *xr_next = row_ptr(has_next ? next : tile);
     int ql = q;
     asm volatile("" : "+v"(ql));
-    if constexpr (!FULL) {
+    if (!full) {
 #pragma unroll
-      for (int c = 0; c < NCH; ++c)
-        if (c == c_last) {
-#pragma unroll
-          for (int j4 = 0; j4 < 4; ++j4) xq[c][j4] = ld4_row_fix(xq[c][j4], 64 * c + 16 * j4 + 4 * ql, D, al4);
-        }
+      for (int j4 = 0; j4 < 4; ++j4) xq[c_last][j4] = ld4_row_fix(xq[c_last][j4], 64 * c_last + 16 * j4 + 4 * ql, D, al4);
     }
     // ---- LayerNorm statistics over the D inputs (exact two-pass on the registers); the inputs become x - mean ----
     float mean = 0.f, rstd = 1.f;
@@ -373,18 +370,19 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
       const f32x4 mean4 = {mean, mean, mean, mean};
       f32x4 v4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) {
-        if (FULL || c < c_last) {
+      for (int c = 0; c < c_last; ++c)
 #pragma unroll
-          for (int j4 = 0; j4 < 4; ++j4) { const f32x4 d = xq[c][j4] - mean4; xq[c][j4] = d; v4 += d * d; }
-        } else if (c == c_last) {
+        for (int j4 = 0; j4 < 4; ++j4) { const f32x4 d = xq[c][j4] - mean4; xq[c][j4] = d; v4 += d * d; }
+      if (full) {
 #pragma unroll
-          for (int j4 = 0; j4 < 4; ++j4) {
-            f32x4 d = xq[c][j4] - mean4;
+        for (int j4 = 0; j4 < 4; ++j4) { const f32x4 d = xq[c_last][j4] - mean4; xq[c_last][j4] = d; v4 += d * d; }
+      } else {                                                  // columns beyond the row stay out of the sum and meet the MFMAs as zeros
 #pragma unroll
-            for (int t = 0; t < 4; ++t) d[t] = (64 * c + 16 * j4 + 4 * ql + t < D) ? d[t] : 0.f;
-            xq[c][j4] = d; v4 += d * d;
-          }
+        for (int j4 = 0; j4 < 4; ++j4) {
+          f32x4 d = xq[c_last][j4] - mean4;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) d[t] = (64 * c_last + 16 * j4 + 4 * ql + t < D) ? d[t] : 0.f;
+          xq[c_last][j4] = d; v4 += d * d;
         }
       }
       rstd = 1.0f / sqrtf(quad_sum16((v4[0] + v4[1]) + (v4[2] + v4[3])) * inv_D + LN_EPS);
@@ -395,30 +393,40 @@ __global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
     for (int bo = 0; bo < 4; ++bo) acc[bo] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      if (FULL || c <= c_last) {
-        const float *Wc = sW + (4 * c * 64 + lane) * 4;          // block (bo, kb = 4 c + jj) at (bo KB + kb) * 256
+      const float *Wc = sW + (4 * c * 64 + lane) * 4;          // block (bo, kb = 4 c + jj) at (bo KB + kb) * 256
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          f32x4 a[4];
+      for (int jj = 0; jj < 4; ++jj) {
+        f32x4 a[4];
 #pragma unroll
-          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + (bo * KB + jj) * 256);
+        for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(Wc + (bo * KB + jj) * 256);
 #pragma unroll
-          for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int bo = 0; bo < 4; ++bo) acc[bo] = WIDE_MFMA(a[bo][t], xq[c][jj][t], acc[bo]);
-        }
-        if (FULL || has_next) load_rows(xr_next, c);           // these 16 registers are free: the next tile's columns
+          for (int bo = 0; bo < 4; ++bo) acc[bo] = WIDE_MFMA(a[bo][t], xq[c][jj][t], acc[bo]);
       }
+      load_rows(xr_next, c);                                   // these 16 registers are free: the next tile's columns (the last tile reloads itself)
     }
     const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
-    if (ok) {
-      if (q == 0 && p.mean0) { p.mean0[i] = mean; p.rstd0[i] = rstd; }
 #pragma unroll
-      for (int b = 0; b < 4; ++b) st4(p.z1 + i * HID + 16 * b + 4 * q, acc[b] * rstd4 + ld4(sB + 16 * b + 4 * q));
-    }
+    for (int b = 0; b < 4; ++b) acc[b] = acc[b] * rstd4 + ld4(sB + 16 * b + 4 * q);
+    tail(acc, i, ok, mean, rstd);
     if (!has_next) break;
     tile = next;
   }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void wide_l1_fwd16_kernel(Wide16Args p) {
+  extern __shared__ __align__(16) float lds[];
+  const int q = (threadIdx.x & 63) >> 4;
+  wide_l1_resident_body<NCH>(p, lds, []() {},
+    [&](f32x4 (&acc)[4], int64_t i, bool ok, float mean, float rstd) __attribute__((always_inline)) {
+      if (ok) {
+        if (q == 0 && p.mean0) { p.mean0[i] = mean; p.rstd0[i] = rstd; }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) st4(p.z1 + i * HID + 16 * b + 4 * q, acc[b]);
+      }
+    });
 }
 
 // Everything the register-resident tail (mlp_fwd16.h) reads from LDS — the per-feature vectors from b1 on, W2.., the head —
@@ -647,6 +655,22 @@ __global__ __launch_bounds__(512, 2) void wide_rollout_full_kernel(WideFullArgs 
       p.mask_dst[e] = p.done[nn * p.done_sn + m * p.done_sm] ? 0.f : 1.f;
     }
   }
+}
+
+// Trunk features of a TRAINING-sized batch (recurrent networks: mappo_mlp_features / _seq, 128 000 rows per minibatch at BASELINE
+// configs[3]): W1' resident as in wide_l1_fwd16_kernel — a workgroup walks enough tiles to amortise staging it whole — and the rest of
+// the trunk from the accumulators of the same tile.  The streamed rollout form (wide_forward16_kernel) pays a chunk fetch + workgroup
+// barrier per 64 columns and tile group: 0.16 of the fp32 MFMA peak at in_dim 322.  LDS: [W1' | b1' | the tail's map without its tiles].
+template <bool RELU, int LN, int NCH>
+__global__ __launch_bounds__(512, 2) void wide_features16_resident_kernel(Wide16Args w, FwdArgs p) {
+  extern __shared__ __align__(16) float lds[];
+  float *lt = lds + HID * 64 * NCH + HID;
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  wide_l1_resident_body<NCH>(w, lds,
+    [&]() __attribute__((always_inline)) { stage_tail_1shot<LN>(lt, p.map, p.params, p.off, p.desc); },
+    [&](f32x4 (&acc)[4], int64_t i, bool ok, float, float) __attribute__((always_inline)) {
+      forward16_tail<RELU, LN, 2>(p, lt, p.map, acc, i, ok, j, q, nullptr);
+    });
 }
 
 // Trunk features of a recurrent actor AND critic with wide inputs in one launch (rollout step: the two networks read different
