@@ -1129,14 +1129,20 @@ struct T16Lds {
   static constexpr int FN_G = B2 + HID, FN_B = FN_G + HID, G1 = FN_B + HID, T1 = G1 + HID, G2 = T1 + HID, T2 = G2 + HID, TOTAL = T2 + HID;
 };
 
-template <bool RELU, int LN>
+// KB1 = ceil(in_dim / 16) is a template parameter (the layer-1 loop has no branches), a row is fetched as KB1 16-byte loads that
+// never leave it (ld4_row_raw: clamped start, lanes shifted and zero-filled at the row end by ld4_row_fix — only the last block can
+// need it), and everything a tile needs from the argument block is copied to locals first.  The first form (sixteen clamped dword
+// loads with 64-bit addresses per lane, a branch per block, 15-17 spilled registers) reloaded spills between the two halves of the
+// next tile's fetch: two exposed memory round trips per tile (118 us per network at BASELINE configs[2] against ~50 of work).
+template <bool RELU, int LN, int KB1>
 __global__ __launch_bounds__(G16_THREADS, 2) void gru16_features_kernel(Feat16Args p) {
   extern __shared__ __align__(16) float lds[];
   typedef T16Lds<LN> M;
   const NetOff &o = p.off;
   const int lane = threadIdx.x & (WAVE - 1), n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)), nw = blockDim.x / WAVE;
-  const int D = p.D, kb1 = (D + 15) >> 4;
+  const int D = p.D;
+  constexpr int kb1 = KB1;
   // ---- staging: W1 [64][D] -> fragment blocks (bo, b < kb1), columns >= D zero; W2; vectors (feature-norm vectors zero beyond D) ----
   for (int e = threadIdx.x; e < HID * kb1 * 4; e += blockDim.x) {
     const int f = e / (kb1 * 4), kq = e - f * (kb1 * 4);
@@ -1160,50 +1166,54 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gru16_features_kernel(Feat16Ar
     lds[M::B1 + e] = v;                                          // B1, B2, FN_G, FN_B, G1, T1, G2, T2 are consecutive
   }
   __syncthreads();
-  const int n_ct = (p.Nc + 15) >> 4;
+  const int Nc = p.Nc, n_ct = (Nc + 15) >> 4;
   const int64_t n_tiles = (int64_t)p.L * n_ct, stride = (int64_t)gridDim.x * nw;
+  const float *const xbase = p.x;
+  const int32_t *const rows = p.rows;
+  float *const out = p.out;
+  const bool fnorm = p.fnorm != 0, al4 = (D & 3) == 0;
   const float inv_D = 1.0f / (float)D;
   int n_pad = 0;                                                  // slots of this lane beyond D (they hold 0)
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
+  for (int b = 0; b < KB1; ++b)
 #pragma unroll
     for (int i = 0; i < 4; ++i) n_pad += (16 * b + 4 * q + i >= D) ? 1 : 0;
-  auto fetch = [&](int64_t tl, f32x4 (&xv)[4]) {
+  auto fetch = [&](int64_t tl, f32x4 (&xv)[KB1]) {
     const int64_t t = tl / n_ct;
     const int c = (int)(tl - t * n_ct) * 16 + n;
-    const int64_t i = t * p.Nc + (c < p.Nc ? c : 0);
-    const int64_t row = p.rows ? (int64_t)p.rows[i] : i;
-    const float *src = p.x + row * D;
+    const int64_t i = t * Nc + (c < Nc ? c : 0);
+    int r = (int)i;
+    if (rows) r = rows[i];
+    const float *src = xbase + (int64_t)r * D;
+    int ql = q;
+    asm volatile("" : "+v"(ql));                                  // (offsets recomputed per call, not kept as address pairs)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) xv[b][r] = src[min(16 * b + 4 * q + r, D - 1)];
+    for (int b = 0; b < KB1; ++b) xv[b] = ld4_row_raw(src, 16 * b + 4 * ql, D);
   };
   int64_t tile = (int64_t)blockIdx.x * nw + wave;
   if (tile >= n_tiles) return;
-  f32x4 xn[4];
+  f32x4 xn[KB1];
   fetch(tile, xn);
   for (; tile < n_tiles; tile += stride) {
-    f32x4 x[4];
+    f32x4 x[KB1];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) x[b][i] = (16 * b + 4 * q + i < D) ? xn[b][i] : 0.f;
+    for (int b = 0; b < KB1; ++b) x[b] = xn[b];
+    x[KB1 - 1] = ld4_row_fix(x[KB1 - 1], 16 * (KB1 - 1) + 4 * q, D, al4);      // (blocks before the last are inside the row)
     fetch(min(tile + stride, n_tiles - 1), xn);
-    if (p.fnorm) {
+    if (fnorm) {
       float s = 0.f;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) s += (x[b][0] + x[b][1]) + (x[b][2] + x[b][3]);
+      for (int b = 0; b < KB1; ++b) s += (x[b][0] + x[b][1]) + (x[b][2] + x[b][3]);
       const float mean = quad_sum16(s) * inv_D;
       float v = 0.f;
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < KB1; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { const float cdev = x[b][i] - mean; x[b][i] = cdev; v += cdev * cdev; }
       v -= (float)n_pad * mean * mean;                            // the padded slots contributed (0 - mean)^2 each
       const float rstd = 1.0f / sqrtf(fmaxf(quad_sum16(v), 0.f) * inv_D + LN_EPS);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
+      for (int b = 0; b < KB1; ++b) {
         const f32x4 g = ld4(lds + M::FN_G + 16 * b + 4 * q), t = ld4(lds + M::FN_B + 16 * b + 4 * q);
         x[b] = x[b] * f32x4{rstd, rstd, rstd, rstd} * g + t;     // gamma = beta = 0 beyond D: padded slots are exactly 0
       }
@@ -1214,16 +1224,14 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gru16_features_kernel(Feat16Ar
     {
       const float *base = lds + M::W1 + lane * 4;
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b < kb1) {
-          f32x4 a[4];
+      for (int b = 0; b < KB1; ++b) {
+        f32x4 a[4];
 #pragma unroll
-          for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(base + (bo * kb1 + b) * 256);
+        for (int bo = 0; bo < 4; ++bo) a[bo] = ld4(base + (bo * kb1 + b) * 256);
 #pragma unroll
-          for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int bo = 0; bo < 4; ++bo) h[bo] = mfma16(a[bo][i], x[b][i], h[bo]);
-        }
+          for (int bo = 0; bo < 4; ++bo) h[bo] = mfma16(a[bo][i], x[b][i], h[bo]);
       }
     }
     act_ln16<RELU>(h, lds + M::G1, lds + M::T1, q);
@@ -1237,7 +1245,7 @@ __global__ __launch_bounds__(G16_THREADS, 2) void gru16_features_kernel(Feat16Ar
       for (int b = 0; b < 4; ++b) h[b] = h2[b];
     }
 #pragma unroll
-    for (int b = 0; b < 4; ++b) st4(p.out + (tile * 4 + b) * 256 + lane * 4, h[b]);
+    for (int b = 0; b < 4; ++b) st4(out + (tile * 4 + b) * 256 + lane * 4, h[b]);
   }
 }
 
@@ -1304,7 +1312,13 @@ int mlp_features_blocked_wide_(const float *params, const mappo_net_desc *desc, 
                                float *out_blocked, mappo_stream_t stream);      // mlp.hip
 template <bool RELU, int LN>
 static int feat16_launch(const Feat16Args &a, dim3 grid, dim3 block, hipStream_t st) {
-  hipLaunchKernelGGL((gru16_features_kernel<RELU, LN>), grid, block, (size_t)T16Lds<LN>::TOTAL * sizeof(float), st, a);
+  const size_t lb = (size_t)T16Lds<LN>::TOTAL * sizeof(float);
+  switch ((a.D + 15) / 16) {
+    case 1: hipLaunchKernelGGL((gru16_features_kernel<RELU, LN, 1>), grid, block, lb, st, a); break;
+    case 2: hipLaunchKernelGGL((gru16_features_kernel<RELU, LN, 2>), grid, block, lb, st, a); break;
+    case 3: hipLaunchKernelGGL((gru16_features_kernel<RELU, LN, 3>), grid, block, lb, st, a); break;
+    default: hipLaunchKernelGGL((gru16_features_kernel<RELU, LN, 4>), grid, block, lb, st, a); break;
+  }
   return MAPPO_OK;
 }
 
@@ -1314,8 +1328,8 @@ extern "C" int mappo_mlp_features_seq(const float *params, const mappo_net_desc 
   MAPPO_REQUIRE(params && x && out_blocked && L > 0 && Nc > 0, "mlp_features_seq: bad arguments");
   if (desc->in_dim > MAXD)       // wide inputs (Nc % 16 == 0): the one-launch wide forward writes the same blocked form (mlp.hip)
     return mlp_features_blocked_wide_(params, desc, x, rows, (int64_t)L * Nc, out_blocked, stream);
-  MAPPO_REQUIRE(desc->in_dim >= 1 && desc->layer_N >= 0 && desc->layer_N <= 1,
-                "mlp_features_seq: layer_N %d takes mappo_mlp_features (feature-major)", desc->layer_N);
+  MAPPO_REQUIRE(desc->in_dim >= 4 && desc->layer_N >= 0 && desc->layer_N <= 1,
+                "mlp_features_seq: in_dim %d < 4 / layer_N %d take mappo_mlp_features (feature-major)", desc->in_dim, desc->layer_N);
   MAPPO_CLEAR_STICKY();
   Feat16Args a = {};
   a.params = params; a.off = net_offsets(*desc); a.x = x; a.rows = rows; a.L = L; a.Nc = Nc; a.D = desc->in_dim;
@@ -1323,7 +1337,9 @@ extern "C" int mappo_mlp_features_seq(const float *params, const mappo_net_desc 
   const int64_t n_tiles = (int64_t)L * ((Nc + 15) / 16);
   const int nw = n_tiles >= 8 * NUM_CU ? 8 : (n_tiles >= 4 * NUM_CU ? 4 : (n_tiles >= 4 ? 4 : 1));
   int64_t nb = (n_tiles + nw - 1) / nw;
-  if (nb > NUM_CU) nb = NUM_CU;
+  int64_t cap = NUM_CU;                                          // (two / four workgroups per CU fit now — measured no better: 21.9 / 22.0 / 22.1 ms
+  if (const char *e = getenv("MAPPO_FEAT16_GRID")) cap = atoll(e);      //  of config-3 train at 256 / 512 / 1024; A/B override)
+  if (nb > cap) nb = cap;
   const dim3 grid((unsigned)nb), block(WAVE * nw);
   const bool relu = desc->use_relu != 0;
   if (desc->layer_N == 0) { if (relu) feat16_launch<true, 0>(a, grid, block, as_stream(stream)); else feat16_launch<false, 0>(a, grid, block, as_stream(stream)); }

@@ -25,35 +25,6 @@
 #define WIDE_MFMA(a, b, c) mfma16(a, b, c)
 #endif
 
-// Elements k .. k + 3 of a row of D floats (D >= 4) as one 16-byte load that never leaves the row: the load starts at
-// min(k, D - 4) (ld4_row_raw) and the lanes are shifted down by the difference, zeros beyond the row (ld4_row_fix — separate,
-// so that the load can stay in flight).  Rows need 4-byte alignment only (global_load_dwordx4 takes any dword address); with
-// D % 4 == 0 and k % 4 == 0 the shift is 0 or >= 4 (all zero).
-typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ f32x4 ld4_row_raw(const float *row, int k, int D) {
-  const f32x4_u l = *reinterpret_cast<const f32x4_u *>(row + min(k, D - 4));
-  f32x4 r; r[0] = l[0]; r[1] = l[1]; r[2] = l[2]; r[3] = l[3];
-  return r;
-}
-__device__ __forceinline__ f32x4 ld4_row_fix(const f32x4 l, int k, int D, bool al4) {
-  // bit masks, not selects: nested selects on a per-lane shift come out as divergent branches
-  const int s = k - min(k, D - 4);
-  const uint32_t l0 = __float_as_uint(l[0]), l1 = __float_as_uint(l[1]), l2 = __float_as_uint(l[2]), l3 = __float_as_uint(l[3]);
-  const uint32_t m0 = s == 0 ? ~0u : 0u;
-  f32x4 r;
-  if (al4) {
-    r[0] = __uint_as_float(l0 & m0); r[1] = __uint_as_float(l1 & m0); r[2] = __uint_as_float(l2 & m0); r[3] = __uint_as_float(l3 & m0);
-  } else {
-    const uint32_t m1 = s == 1 ? ~0u : 0u, m2 = s == 2 ? ~0u : 0u, m3 = s == 3 ? ~0u : 0u;
-    r[0] = __uint_as_float((l0 & m0) | (l1 & m1) | (l2 & m2) | (l3 & m3));
-    r[1] = __uint_as_float((l1 & m0) | (l2 & m1) | (l3 & m2));
-    r[2] = __uint_as_float((l2 & m0) | (l3 & m1));
-    r[3] = __uint_as_float(l3 & m0);
-  }
-  return r;
-}
-__device__ __forceinline__ f32x4 ld4_row(const float *row, int k, int D, bool al4) { return ld4_row_fix(ld4_row_raw(row, k, D), k, D, al4); }
-
 // b1'[f] = b1[f] + sum_k W1[f][k] beta0[k]   (64 rows x TPR threads: the whole workgroup)
 template <int TPR>
 __device__ __forceinline__ void wide16_fold_bias(const Wide16Args &p, float *sB) {

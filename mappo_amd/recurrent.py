@@ -185,7 +185,7 @@ def _update_recurrent(tr, src, rows, h0_rows, L, Nc, update_actor, epochs=None):
     def one_net(net, x, h0, head, part, col0, tag):          # 16-sequence-tile kernels (gru_train16.hip)
         # blocked trunk features / d x (one contiguous KiB per wave access): narrow inputs always, wide ones when the sequence count
         # is a multiple of 16 (the flat 16-row tiles of the wide kernels then are the (t, 16 sequences) tiles)
-        narrow = net.desc.layer_N <= 1 and (net.desc.in_dim <= 64 or (net.desc.in_dim <= 512 and Nc % 16 == 0 and _WIDE_BLOCKED))
+        narrow = net.desc.layer_N <= 1 and (4 <= net.desc.in_dim <= 64 or (64 < net.desc.in_dim <= 512 and Nc % 16 == 0 and _WIDE_BLOCKED))
         s = _scratch.get16(dev, L, Nc, tag, narrow)
         if narrow:
             ops.mlp_features_seq(net.flat, net.desc, x, rows, L, Nc, s["feat"])
