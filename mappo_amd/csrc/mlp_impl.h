@@ -82,6 +82,27 @@ __host__ __device__ inline LdsMap lds_map(const mappo_net_desc &d, int n_waves) 
   return m;
 }
 
+// The part of the map the register-resident tail (mlp_fwd16.h: forward16_tail after stage_tail_1shot) reads — no W1 chunk area, no
+// feature-norm vectors, no per-wave tiles: what a kernel that keeps W1' elsewhere in LDS puts behind it (wide_features16_resident_kernel).
+__host__ __device__ inline LdsMap lds_map_tail(const mappo_net_desc &d) {
+  LdsMap m = lds_map(d, 1);
+  int p = 0;
+  m.w1 = 0; m.fn_w = 0; m.fn_b = 0; m.fn_size = 0;
+  for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) { m.w2[l] = p; if (l < d.layer_N) p = al4(p + HID * WP); }
+  m.wh = p; p = al4(p + HID * HP);
+  m.b1 = p; p += HID; m.ln1_w = p; p += HID; m.ln1_b = p; p += HID;
+  for (int l = 0; l < MAPPO_MAX_LAYER_N; ++l) {
+    m.b2[l] = p; m.ln2_w[l] = p; m.ln2_b[l] = p;
+    if (l < d.layer_N) { m.b2[l] = p; p += HID; m.ln2_w[l] = p; p += HID; m.ln2_b[l] = p; p += HID; }
+  }
+  m.bh = p; p += 32;
+  m.scratch = p;
+  m.tiles = p;
+  m.wave_stride = 0;
+  m.total = p;
+  return m;
+}
+
 // Workgroup-cooperative staging of one weight matrix: global W[f][k] (row-major, K columns) -> LDS dst[k*stride + f],
 // rows k in [K, Kpad) zeroed.  Loads are UNCONDITIONAL (clamped index) and all issued before the first LDS write, so a
 // thread pays one memory latency for its whole share (a predicated load is waited for individually by hipcc).
@@ -2047,8 +2068,12 @@ static int launch_forward(const FwdArgs &a_in, hipStream_t st, const char *who) 
         return MAPPO_OK;
       }
       // trunk features of a training-sized batch: W1' resident (wide_features16_resident_kernel); MAPPO_WIDE_RESIDENT=0: streamed (A/B)
-      if (MODE == 2 && LN <= 1 && nt16 >= 2 * 8 * NUM_CU && !(getenv("MAPPO_WIDE_RESIDENT") && atoi(getenv("MAPPO_WIDE_RESIDENT")) == 0)) {
-        const int rcr = a.desc.use_relu ? wide16_launch_features_resident_r<true>(LN, g2, st, w, a) : wide16_launch_features_resident_r<false>(LN, g2, st, w, a);
+      FwdArgs ar = a;
+      ar.map = lds_map_tail(a.desc);
+      const size_t lres = sizeof(float) * ((size_t)HID * 64 * ((a.desc.in_dim + 63) / 64) + HID + ar.map.tiles);
+      if (MODE == 2 && LN <= 1 && nt16 >= 2 * 8 * NUM_CU && lres <= 159 * 1024 &&
+          !(getenv("MAPPO_WIDE_RESIDENT") && atoi(getenv("MAPPO_WIDE_RESIDENT")) == 0)) {
+        const int rcr = a.desc.use_relu ? wide16_launch_features_resident_r<true>(LN, g2, st, w, ar) : wide16_launch_features_resident_r<false>(LN, g2, st, w, ar);
         if (rcr) return rcr;
         MAPPO_CHECK_LAUNCH(who);
         return MAPPO_OK;

@@ -308,6 +308,42 @@ def test_mlp_forward_vs_oracle(ops, D, A, relu, LN, fn, B):
     np.testing.assert_array_equal(out.cpu().numpy(), out2.cpu().numpy())
 
 
+@pytest.mark.parametrize("D,LN,relu,fn", [(65, 1, True, True), (128, 1, True, True), (130, 0, True, True), (200, 1, False, True), (256, 1, True, False),
+                                          (300, 1, True, True), (322, 1, True, True), (400, 1, True, True), (448, 0, False, True), (511, 1, True, True),
+                                          (512, 1, True, True)])
+def test_wide_trunk_features_resident_kernel_every_chunk_count(ops, monkeypatch, D, LN, relu, fn):
+    """Trunk features of a training-sized batch of a wide-input recurrent network (mappo_mlp_features_seq -> wide_features16_resident_kernel,
+    W1' resident, the chunk count ceil(D / 64) = 2..8 a template parameter, row ends inside the last chunk at D % 64 != 0 and D % 4 != 0)
+    vs the reference trunk (mlp.py:18-55) on a strided subset of rows, and vs the streamed kernel (MAPPO_WIDE_RESIDENT=0) on all rows."""
+    L, Nc = 8, 8192 + 16                                   # 65 664 rows = 4 104 tiles (>= 4 096: the resident kernel's threshold)
+    B = L * Nc
+    torch.manual_seed(D)
+    a = O.default_args(use_ReLU=relu, layer_N=LN, use_feature_normalization=fn)
+    net = O.CriticRef(a, D)
+    _randomize(net, D + 3)
+    desc = ops.net_desc(D, 1, LN, relu, fn)
+    params, _, _ = _flat_from_module(ops, net, desc, "v_out")
+    g = torch.Generator(device="cuda").manual_seed(D + 1)
+    n_rows = B + 64
+    x = torch.randn(n_rows, D, device="cuda", generator=g) * 1.5 + 0.25
+    rows = torch.randperm(n_rows, device="cuda", generator=g)[:B].to(torch.int32)
+    outs = []
+    for res in ("1", "0"):
+        monkeypatch.setenv("MAPPO_WIDE_RESIDENT", res)
+        feat = torch.full((ops.gru16_blocked_floats(L, Nc),), float("nan"), device="cuda")
+        ops.mlp_features_seq(params, desc, x, rows, L, Nc, feat)
+        torch.cuda.synchronize()
+        outs.append(feat.view(L * (Nc // 16), 4, 4, 16, 4))          # [tile][b][q][n][i]: feature 16 b + 4 q + i of sample 16 tile + n
+    f1 = outs[0].permute(0, 3, 1, 2, 4).reshape(B, 64)               # -> [row][feature]
+    f0 = outs[1].permute(0, 3, 1, 2, 4).reshape(B, 64)
+    np.testing.assert_allclose(f1.cpu().numpy(), f0.cpu().numpy(), rtol=1e-5, atol=1e-5)      # (different summation orders through two LayerNorms)
+    sel = torch.arange(0, B, 97, device="cuda")
+    with torch.no_grad():
+        ref = net.base(x[rows.long()[sel]].cpu()).numpy() if hasattr(net, "base") else None
+    assert ref is not None
+    close(f1[sel], ref, 1e-5, 2e-5, f"resident features D={D}")
+
+
 def test_forward_golden_reference_outputs(ops):
     """get_actions(deterministic) / get_values / evaluate_actions of the reference itself (golden forward c0, c1)."""
     g = golden("forward")
@@ -460,7 +496,9 @@ def _relu_margin(net, x):
                                                     # mlp_update16x_kernel / wide_l1_bwd16_kernel walk several tiles per wave
                                                     # (configs[3] / configs[4] sizes; ragged last tile; gathered rows in the second)
                                                     (512, 512, 5, True, 70001, False), (176, 322, 18, True, 47019, True),
-                                                    (130, 65, 3, False, 33333, False)])
+                                                    (130, 65, 3, False, 33333, False),
+                                                    # the remaining exact chunk counts of wide_l1_fwd16_kernel (4, 5, 7 chunks; in_dim % 4 != 0)
+                                                    (256, 300, 5, True, 33011, True), (448, 401, 4, True, 33017, False)])
 def test_fused_update_kernels_vs_unfused_and_autograd(ops, D, S, A, relu, B, with_rows):
     """mappo_actor_update / mappo_critic_update (forward + in-kernel PPO loss + backward in one launch) against
     (a) the standalone sequence mlp_forward -> ppo_loss_fwd_bwd -> mlp_backward and (b) torch autograd through
