@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from scripts.bench_configs import make_runner
 
-r = make_runner("c3")
+r = make_runner(os.environ.get("PMC_CFG", "c3"))
 r.trainer.ppo_epoch = 2
 r.trainer._use_graph = False
 r.warmup()
