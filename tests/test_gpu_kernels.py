@@ -758,7 +758,10 @@ def test_wide_full_rollout_step_matches_streamed_and_separate_insert(ops, monkey
     A = 5
     R = N * M
     g = torch.Generator(device="cuda").manual_seed(D + N)
-    obs = torch.randn(N, M, D, device="cuda", generator=g) * 1.5 + 0.3
+    if N % 2:                                              # the env's output as a strided view (thread stride M D + 1: rows 4-byte aligned only)
+        obs = (torch.randn(N, M * D + 1, device="cuda", generator=g) * 1.5 + 0.3)[:, :M * D].view(N, M, D)
+    else:
+        obs = torch.randn(N, M, D, device="cuda", generator=g) * 1.5 + 0.3
     rew = torch.randn(N, 1, device="cuda", generator=g).expand(N, M)
     dones = torch.rand(N, M, device="cuda", generator=g) > 0.5
     da, dc = ops.net_desc(D, A), ops.net_desc(D, 1)
