@@ -670,9 +670,13 @@ struct SkShared {
   float4 sAcc[3][4][64];                                      // partial accumulators of waves 1..3
 };
 
-template <bool RELU, int LN, int MODE>
+struct SkNoHook { __device__ __forceinline__ void operator()() const {} };
+// after_loads(): called once, when the first tile's weight and row loads are out — loads the CALLER needs later (the GRU step's
+// weights in the fused recurrent step) go behind them: the counter is in order, so what is requested first is what the first MFMA
+// waits for
+template <bool RELU, int LN, int MODE, class Hook = SkNoHook>
 __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, const FwdArgs &p, float *lds, SkShared &sh, const int bid, const int nb,
-                                                       float *xshare = nullptr) {      // MODE 4: the trunk output goes to xshare[4][64] float4
+                                                       float *xshare = nullptr, Hook &&after_loads = Hook()) {      // MODE 4: the trunk output goes to xshare[4][64] float4
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int D = w.D;
@@ -718,8 +722,10 @@ __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, cons
       for (int jj = 0; jj < 4; ++jj)
         xq[j][jj] = (c <= c_last) ? ld4_row(xr, 64 * c + 16 * jj + 4 * q, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    if (tile == bid)       // first tile: the tail's weights (everything but W1) go to LDS behind the loads above — one memory latency in all
+    if (tile == bid) {     // first tile: the tail's weights (everything but W1) go to LDS behind the loads above — one memory latency in all
+      after_loads();
       stage_tail_1shot<LN>(lds, p.map, p.params, p.off, p.desc);
+    }
     if (fnorm) {
       f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -833,13 +839,15 @@ __global__ __launch_bounds__(256, 1) void wide_recurrent_step_dual_kernel(WideRe
   const int bid = actor ? (int)blockIdx.x : (int)blockIdx.x - r.d.nA, nb = r.d.nA;
   if ((int)blockIdx.x >= 2 * r.d.nA) { insert_smac_body(r.ins, (int)blockIdx.x - 2 * r.d.nA, r.nI); return; }
   Step3W<0> W;
+  // (the GRU step's 96 weight registers are requested BEHIND the trunk's own weights and rows: asked for first, they were what the
+  // trunk's first MFMA waited for)
   if (actor) {
-    gru_step3_load<3, 0>(W, r.ga, wv, n, q);
-    wide_forward16_sk_body<RELU, LN, 4>(r.d.wa, r.d.a, lds, sh, bid, nb, reinterpret_cast<float *>(sX));
+    wide_forward16_sk_body<RELU, LN, 4>(r.d.wa, r.d.a, lds, sh, bid, nb, reinterpret_cast<float *>(sX),
+                                        [&]() __attribute__((always_inline)) { gru_step3_load<3, 0>(W, r.ga, wv, n, q); });
     gru_step3_tiles<2, 3, 0>(W, r.ga, s3, bid, nb, sX);
   } else {
-    gru_step3_load<3, 0>(W, r.gc, wv, n, q);
-    wide_forward16_sk_body<RELU, LN, 4>(r.d.wc, r.d.c, lds, sh, bid, nb, reinterpret_cast<float *>(sX));
+    wide_forward16_sk_body<RELU, LN, 4>(r.d.wc, r.d.c, lds, sh, bid, nb, reinterpret_cast<float *>(sX),
+                                        [&]() __attribute__((always_inline)) { gru_step3_load<3, 0>(W, r.gc, wv, n, q); });
     gru_step3_tiles<1, 3, 0>(W, r.gc, s3, bid, nb, sX);
   }
 }
