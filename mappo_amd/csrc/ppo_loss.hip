@@ -13,6 +13,13 @@
 #include "common.h"
 #include <float.h>
 
+// exp / log on the hardware transcendental units (v_exp_f32 / v_log_f32, 1 ulp) as in the fused update kernels (mlp_upd16.h): the
+// libm forms are ~20-25 instructions each, 2 A + 2 of them per sample — at configs[4] size (6.5 M samples) 45 % of this kernel's time
+// was their arithmetic, on a kernel whose roofline is the HBM stream.  Arguments are differences from the running max / old
+// log-probs (bounded), results feed sums and products of the same 1e-5 tolerance class.
+__device__ __forceinline__ float pl_exp(float x) { return __builtin_amdgcn_exp2f(1.44269504088896341f * x); }
+__device__ __forceinline__ float pl_log(float x) { return 0.693147180559945309f * __builtin_amdgcn_logf(x); }
+
 #define PL_BLOCK 256
 #define PL_MAX_BLOCKS 65535
 
@@ -93,20 +100,20 @@ __global__ __launch_bounds__(PL_BLOCK) void ppo_loss_kernel(PlArgs p) {
       const bool small = A <= 8;
       float se = 0.f;
 #pragma unroll
-      for (int a = 0; a < 8; ++a) { ereg[a] = 0.f; if (small && a < A) { ereg[a] = expf(z[a] - zmax); se += ereg[a]; } }
-      if (!small) for (int a = 0; a < A; ++a) se += expf(z[a] - zmax);
-      const float log_se = logf(se), inv_se = 1.0f / se;
+      for (int a = 0; a < 8; ++a) { ereg[a] = 0.f; if (small && a < A) { ereg[a] = pl_exp(z[a] - zmax); se += ereg[a]; } }
+      if (!small) for (int a = 0; a < A; ++a) se += pl_exp(z[a] - zmax);
+      const float log_se = pl_log(se), inv_se = 1.0f / se;
       // ---- pass 3: entropy  H = -sum p * max(logp, finfo.min) ----
       float H = 0.f;
       if (small) {
 #pragma unroll
         for (int a = 0; a < 8; ++a) if (a < A) { const float lp = (z[a] - zmax) - log_se; H -= ereg[a] * inv_se * fmaxf(lp, -FLT_MAX); }
       } else {
-        for (int a = 0; a < A; ++a) { const float lp = (z[a] - zmax) - log_se; H -= expf(lp) * fmaxf(lp, -FLT_MAX); }
+        for (int a = 0; a < A; ++a) { const float lp = (z[a] - zmax) - log_se; H -= pl_exp(lp) * fmaxf(lp, -FLT_MAX); }
       }
       // ---- policy surrogate (r_mappo.py:124-134) ----
       const float logp = (z[act] - zmax) - log_se;
-      const float ratio = expf(logp - old_lp);
+      const float ratio = pl_exp(logp - old_lp);
       const float s1 = ratio * adv;
       const float s2 = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip) * adv;
       const float w_pi = p.cfg.use_policy_active_masks ? active : 1.f;
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(PL_BLOCK) void ppo_loss_kernel(PlArgs p) {
         }
       } else {
         for (int a = 0; a < A; ++a) {
-          const float lp = (z[a] - zmax) - log_se, pa = expf(lp);
+          const float lp = (z[a] - zmax) - log_se, pa = pl_exp(lp);
           float g = dlogp * ((a == act ? 1.f : 0.f) - pa) + ce * pa * (lp + H);
           if (dead & (1u << a)) g = 0.f;          // overwritten logits get no gradient
           z[a] = g;
