@@ -150,6 +150,20 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
   int64_t tile = (int64_t)bid * n_waves + wave;
   if (tile >= n_tiles) return;
   const float *P = p.params;
+  // ---- the first tile's rows: requested BEFORE the weights (the counter is in order: what is asked for first arrives first, and
+  // the rows are what the first arithmetic — the feature norm — needs; behind the ~80 weight loads and the selects on the head's
+  // rows they were a second memory round trip after the weights') ----
+  auto load_x = [&](int64_t tl, f32x4 (&xv)[4]) {
+    const int64_t i = tl * 16 + j;
+    const int64_t row = i < p.B ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
+    const int64_t off = p.x_M ? (row / p.x_M) * p.x_sn + (row % p.x_M) * p.x_sm : row * D;
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xv[b][r] = p.x[off + min(16 * b + 4 * q + r, D - 1)];
+  };
+  f32x4 xn[4];
+  load_x(tile, xn);
   // ---- weights and vectors of this lane (issued before the first wait) ----
   Trunk16R<LN> tw;
   trunk16r_load<LN>(tw, P, o, p.desc, j, q);
@@ -172,13 +186,10 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
   for (; tile < n_tiles; tile += (int64_t)nb * n_waves) {
     const int64_t i = tile * 16 + j;
     const bool ok = i < p.B;
-    const int64_t row = ok ? (p.rows ? (int64_t)p.rows[i] : i) : 0;
-    const int64_t off = p.x_M ? (row / p.x_M) * p.x_sn + (row % p.x_M) * p.x_sm : row * D;
     f32x4 x[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) x[b][r] = p.x[off + min(16 * b + 4 * q + r, D - 1)];
+    for (int b = 0; b < 4; ++b) x[b] = xn[b];
+    if (tile + (int64_t)nb * n_waves < n_tiles) load_x(tile + (int64_t)nb * n_waves, xn);      // (a wave with a second tile: its rows under this tile)
     f32x4 h[4];
     trunk16r_apply<RELU, LN>(tw, x, h, D, ok, fnorm, q);
     // ---- head ----
