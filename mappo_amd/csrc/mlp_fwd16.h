@@ -176,11 +176,12 @@ __device__ __forceinline__ void forward16r_body(const FwdArgs &p, float *lds, co
       const int a = 16 * bo + j;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
-        const f32x4 t = ld4ua(P + o.wh + (size_t)min(a, A - 1) * HID + 16 * b + 4 * q);
-        wh[bo][b] = a < A ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        // rows beyond A: a repeat of the last row (clamped index) — their logits are never stored, and a select here would be
+        // an instruction on a value in flight (see trunk16r_load)
+        wh[bo][b] = ld4ua(P + o.wh + (size_t)min(a, A - 1) * HID + 16 * b + 4 * q);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int ar = 16 * bo + 4 * q + r; const float bvv = P[o.bh + min(ar, A - 1)]; bhv[bo][r] = ar < A ? bvv : 0.f; }
+      for (int r = 0; r < 4; ++r) bhv[bo][r] = P[o.bh + min(16 * bo + 4 * q + r, A - 1)];
     }
   }
   for (; tile < n_tiles; tile += (int64_t)nb * n_waves) {

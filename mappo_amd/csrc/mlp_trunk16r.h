@@ -91,11 +91,11 @@ __device__ __forceinline__ void trunk16r_load(Trunk16R<LN> &w, const float *P, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int k = 16 * b + 4 * q + r;
-      const bool in = fnorm && k < D;
       const int ofw = fnorm ? o.fn_w : o.w1, ofb = fnorm ? o.fn_b : o.w1;      // (no feature norm: fn_w / fn_b are -1 — read something valid)
-      const float gv = P[ofw + min(k, D - 1)], tv = P[ofb + min(k, D - 1)];
-      w.g0[b][r] = in ? gv : 0.f;
-      w.t0[b][r] = in ? tv : 0.f;
+      // raw (clamped index): slots beyond in_dim are zeroed where the affine is applied (trunk16r_apply) — a select HERE is an
+      // instruction on a value in flight: the wait for it, and for every load issued before it, lands in front of the tile loop
+      w.g0[b][r] = P[ofw + min(k, D - 1)];
+      w.t0[b][r] = P[ofb + min(k, D - 1)];
     }
 #pragma unroll
   for (int b = 0; b < 4; ++b) { w.b1v[b] = ld4ua(P + o.b1 + 16 * b + 4 * q); w.g1[b] = ld4ua(P + o.ln1_w + 16 * b + 4 * q); w.t1[b] = ld4ua(P + o.ln1_b + 16 * b + 4 * q); }
@@ -133,7 +133,7 @@ __device__ __forceinline__ void trunk16r_apply(const Trunk16R<LN> &w, f32x4 (&x)
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) x[b][r] = x[b][r] * rstd * w.g0[b][r] + w.t0[b][r];
+      for (int r = 0; r < 4; ++r) x[b][r] = (16 * b + 4 * q + r < D) ? x[b][r] * rstd * w.g0[b][r] + w.t0[b][r] : 0.f;
   }
 #pragma unroll
   for (int bo = 0; bo < 4; ++bo) h[bo] = w.b1v[bo];
