@@ -686,25 +686,37 @@ __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, cons
   const int c_last = (D + 63) / 64 - 1;
   const int64_t n_tiles = (w.B + 15) / 16;
   if (bid >= n_tiles) return;                                 // (uniform; never more workgroups than tiles)
-  // ---- this wave's columns: chunks wave, wave + 4; their W1 rows, gamma0, beta0 (zeros beyond the row) ----
+  // ---- the first tile's rows, then this wave's columns (chunks wave, wave + 4): their W1 rows, gamma0, beta0 ----
+  // Everything is requested RAW — loads clamped into the row / to the last chunk, no instruction on a value in flight — and in the
+  // order it is needed: the counter is in order, and a fix-up or a select right behind the loads (as this prologue had them: a
+  // branch per chunk with zeros on its other side) puts the wait for ALL of them in front of the row loads.  The row-end shift /
+  // zero-fill of the weights (ld4_row_fix) happens once, after the statistics exchanges of the first tile.
+  f32x4 xraw[2][4];
+  auto load_rows = [&](int64_t tl) {
+    const int64_t i = tl * 16 + n;
+    const int64_t row = i < w.B ? (w.rows ? (int64_t)w.rows[i] : i) : 0;
+    const float *xr = w.x + row * D;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = min(wave + 4 * j, c_last);
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) xraw[j][jj] = ld4_row_raw(xr, 64 * c + 16 * jj + 4 * q, D);
+    }
+  };
+  load_rows(bid);
   f32x4 A[2][4][4];                                           // [chunk j][bo][jj]: W1[16 bo + n][64 c + 16 jj + 4 q .. + 3]
   f32x4 gam[2][4], bet[2][4];
+  const float *gsrc = fnorm ? w.params + w.fn_w : w.params + w.w1, *bsrc = fnorm ? w.params + w.fn_b : w.params + w.w1;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int c = wave + 4 * j;
+    const int c = min(wave + 4 * j, c_last);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int k = 64 * c + 16 * jj + 4 * q;
-      if (c <= c_last) {
 #pragma unroll
-        for (int bo = 0; bo < 4; ++bo) A[j][bo][jj] = ld4_row(w.params + w.w1 + (size_t)(16 * bo + n) * D, k, D, al4);
-        gam[j][jj] = fnorm ? ld4_row(w.params + w.fn_w, k, D, al4) : f32x4{1.f, 1.f, 1.f, 1.f};
-        bet[j][jj] = fnorm ? ld4_row(w.params + w.fn_b, k, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      } else {
-#pragma unroll
-        for (int bo = 0; bo < 4; ++bo) A[j][bo][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gam[j][jj] = f32x4{0.f, 0.f, 0.f, 0.f}; bet[j][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      for (int bo = 0; bo < 4; ++bo) A[j][bo][jj] = ld4_row_raw(w.params + w.w1 + (size_t)(16 * bo + n) * D, k, D);
+      gam[j][jj] = ld4_row_raw(gsrc, k, D);
+      bet[j][jj] = ld4_row_raw(bsrc, k, D);
     }
   }
   const int jq = lane & 15;
@@ -712,16 +724,15 @@ __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, cons
   for (int64_t tile = bid; tile < n_tiles; tile += nb) {
     const int64_t i = tile * 16 + n;
     const bool ok = i < w.B;
-    const int64_t row = ok ? (w.rows ? (int64_t)w.rows[i] : i) : 0;
-    const float *xr = w.x + row * D;
     f32x4 xq[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int c = wave + 4 * j;
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
-        xq[j][jj] = (c <= c_last) ? ld4_row(xr, 64 * c + 16 * jj + 4 * q, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        xq[j][jj] = (c <= c_last) ? ld4_row_fix(xraw[j][jj], 64 * c + 16 * jj + 4 * q, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if (tile + nb < n_tiles) load_rows(tile + nb);             // (a workgroup with a second tile: its rows under this one)
     if (tile == bid) {     // first tile: the tail's weights (everything but W1) go to LDS behind the loads above — one memory latency in all
       after_loads();
       stage_tail_1shot<LN>(lds, p.map, p.params, p.off, p.desc);
@@ -756,10 +767,35 @@ __device__ __forceinline__ void wide_forward16_sk_body(const Wide16Args &w, cons
       __syncthreads();
       const float rstd = 1.0f / sqrtf(((sh.sV[0][n] + sh.sV[1][n]) + (sh.sV[2][n] + sh.sV[3][n])) * inv_D + LN_EPS);
       const f32x4 rstd4 = {rstd, rstd, rstd, rstd};
+      if (tile == bid) {                                        // (once: the raw feature-norm vectors -> shifted / zero-filled at the row end)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = wave + 4 * j;
+          if (c >= c_last) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+              const int k = 64 * c + 16 * jj + 4 * q;
+              gam[j][jj] = c == c_last ? ld4_row_fix(gam[j][jj], k, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
+              bet[j][jj] = c == c_last ? ld4_row_fix(bet[j][jj], k, D, al4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) xq[j][jj] = xq[j][jj] * rstd4 * gam[j][jj] + bet[j][jj];
+    }
+    if (tile == bid) {                                          // (once: the raw W1 columns of the row-end chunk; chunks beyond it are skipped below)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if (wave + 4 * j == c_last) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int bo = 0; bo < 4; ++bo) A[j][bo][jj] = ld4_row_fix(A[j][bo][jj], 64 * c_last + 16 * jj + 4 * q, D, al4);
+        }
+      }
     }
     f32x4 acc[4];
 #pragma unroll
