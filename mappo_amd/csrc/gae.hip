@@ -14,7 +14,7 @@
 // 16 B (20 B with bad_masks) per agent-step, read once and written once.
 #include "common.h"
 
-#define GAE_LMAX 32   // steps of one segment held in registers
+#define GAE_LMAX 16   // steps of one segment held in registers (three to four loaded values per step, all requested up front)
 #define GAE_SMAX 16   // segments (waves) per block
 
 template <bool USE_GAE, bool PTL>
@@ -36,25 +36,37 @@ __global__ __launch_bounds__(64 * GAE_SMAX) void gae_scan_kernel(
   }
   __syncthreads();
 
+  const int rc = valid ? r : R - 1;                              // (lanes beyond R read the last series: nothing of theirs is stored)
+  const float nv_last = next_value[rc];
   for (int base = ((T - 1) / chunk) * chunk; base >= 0; base -= chunk) {
     const int t0 = base + seg * Lseg;
     const int len = max(0, min(T, t0 + Lseg) - t0);
-    float c[GAE_LMAX], d[GAE_LMAX], vd[GAE_LMAX];
+    // ---- every load of the segment first: unconditional, time index clamped into the episode, nothing computed from a loaded
+    // value until all are out (read inside the composition loop each step was two dependent memory round trips: 2 x 25 of them in
+    // series per wave at T = 400) ----
+    float c[GAE_LMAX], d[GAE_LMAX], vd[GAE_LMAX], bm[PTL ? GAE_LMAX : 1];
+#pragma unroll
+    for (int i = 0; i < GAE_LMAX; ++i) {
+      const size_t o = (size_t)min(t0 + i, T - 1) * R + rc;
+      d[i] = rewards[o];
+      c[i] = masks[o + R];
+      vd[i] = value_preds[o];
+      if (PTL) bm[i] = bad_masks[o + R];
+    }
+    // value of the step after the segment (t0 + len < T: from the buffer; == T: next_value — slot T of value_preds is being
+    // written by this very launch)
+    const float vend_raw = value_preds[(size_t)min(t0 + len, T - 1) * R + rc];
+    const float vend = ((t0 + len >= T) ? nv_last : vend_raw) * vn.sd + vn.mean;
     float C = 1.f, D = 0.f;
 #pragma unroll
     for (int i = GAE_LMAX - 1; i >= 0; --i) {
-      c[i] = 1.f; d[i] = 0.f; vd[i] = 0.f;
+      const float rw = d[i], m1 = c[i], b1 = PTL ? bm[i] : 1.f;
+      const float v_t = vd[i] * vn.sd + vn.mean;
+      const float v_n = (i + 1 < GAE_LMAX && i + 1 < len) ? vd[(i + 1 < GAE_LMAX) ? i + 1 : i] : vend;      // (vd[i + 1] is already denormalised: the loop runs downwards)
+      c[i] = 1.f; d[i] = 0.f; vd[i] = v_t;
       if (i < len && valid) {
-        const int t = t0 + i;
-        const size_t o = (size_t)t * R + r, o1 = o + R;
-        const float rw = rewards[o];
-        const float m1 = masks[o1];
-        const float b1 = PTL ? bad_masks[o1] : 1.f;
-        const float v_t = value_preds[o] * vn.sd + vn.mean;
         float ci, di;
         if (USE_GAE) {
-          const float vraw = (t + 1 == T) ? next_value[r] : value_preds[o1];
-          const float v_n = vraw * vn.sd + vn.mean;
           const float delta = rw + gamma * v_n * m1 - v_t;
           ci = gamlam * m1;
           di = delta;
@@ -64,7 +76,7 @@ __global__ __launch_bounds__(64 * GAE_SMAX) void gae_scan_kernel(
           di = rw;
           if (PTL) { ci *= b1; di = rw * b1 + (1.f - b1) * v_t; }
         }
-        c[i] = ci; d[i] = di; vd[i] = v_t;
+        c[i] = ci; d[i] = di;
         D = di + ci * D;   // compose step t in front of the steps after it
         C = ci * C;
       }
@@ -99,7 +111,7 @@ extern "C" int mappo_gae_scan(const float *rewards, float *value_preds, const fl
   if (S > GAE_SMAX) S = GAE_SMAX;
   if (S < 1) S = 1;
   int Lseg = (T + S - 1) / S;
-  if (Lseg > GAE_LMAX) Lseg = GAE_LMAX;   // long episodes: the block walks several chunks of S*32 steps
+  if (Lseg > GAE_LMAX) Lseg = GAE_LMAX;   // long episodes: the block walks several chunks of S * GAE_LMAX steps
   const float gamlam = (float)((double)gamma * (double)gae_lambda);
   dim3 grid((R + WAVE - 1) / WAVE), block(WAVE * S);
   hipStream_t st = as_stream(stream);
